@@ -1,0 +1,235 @@
+"""ctypes binding of oracle/liboxmpl_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (oxmpl_amd/) never does.  PARITY UNPINNED: see
+oracle/rrt_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboxmpl_oracle.so")
+
+SOLVED, TIMEOUT, NO_SOLUTION_FOUND, PLANNER_UNINITIALISED = 0, 1, 2, 3
+BAD_ARG, UNBOUNDED, ZERO_VOLUME = 16, 17, 18
+STOP_GOAL, STOP_ITERATIONS, STOP_NODES, STOP_TIMEOUT = 0, 1, 2, 3
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("rrt_oracle.c", "rrt_oracle.h", "Makefile")]
+    if (not force) and os.path.exists(_LIB_PATH) and all(
+            os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _LIB_PATH
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_chacha_block.argtypes = [C.POINTER(C.c_uint32), C.c_uint64, C.c_uint64, C.c_int,
+                                       C.POINTER(C.c_uint32)]
+        L.orc_rng_seed.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.orc_rng_next_u64.argtypes = [C.c_void_p]
+        L.orc_rng_next_u64.restype = C.c_uint64
+        L.orc_random_bool.argtypes = [C.c_void_p, C.c_double]
+        L.orc_random_range.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_random_range.restype = C.c_double
+        L.orc_bernoulli_p_int.argtypes = [C.c_double]
+        L.orc_bernoulli_p_int.restype = C.c_uint64
+        L.orc_distance.argtypes = [_dp, _dp, C.c_uint32]
+        L.orc_distance.restype = C.c_double
+        L.orc_interpolate.argtypes = [_dp, _dp, C.c_double, _dp, C.c_uint32]
+        L.orc_maximum_extent.argtypes = [_dp, C.c_uint32]
+        L.orc_maximum_extent.restype = C.c_double
+        L.orc_clamp_fraction.argtypes = [C.c_double]
+        L.orc_clamp_fraction.restype = C.c_double
+        L.orc_num_steps.argtypes = [C.c_double, C.c_double]
+        L.orc_num_steps.restype = C.c_uint64
+        L.orc_rrt_new.argtypes = [C.c_uint32, _dp, C.c_double, C.c_double, C.c_double, C.c_uint32,
+                                  C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
+        L.orc_rrt_new.restype = C.c_void_p
+        L.orc_rrt_free.argtypes = [C.c_void_p]
+        L.orc_rrt_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.orc_rrt_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.orc_rrt_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.orc_rrt_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double]
+        L.orc_rrt_num_nodes.argtypes = [C.c_void_p]
+        L.orc_rrt_num_nodes.restype = C.c_uint32
+        for name in ("orc_rrt_iterations", "orc_rrt_checksum", "orc_rrt_accepted"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint64
+        L.orc_rrt_goal_node.argtypes = [C.c_void_p]
+        L.orc_rrt_goal_node.restype = C.c_int32
+        L.orc_rrt_stop_reason.argtypes = [C.c_void_p]
+        L.orc_rrt_stop_reason.restype = C.c_int32
+        L.orc_rrt_get_tree.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int32)]
+        L.orc_rrt_get_path.argtypes = [C.c_void_p, _dp, C.c_uint32]
+        L.orc_rrt_get_path.restype = C.c_uint32
+        L.orc_rrt_check_motion.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_rrt_is_valid.argtypes = [C.c_void_p, _dp]
+        L.orc_nearest.argtypes = [_dp, C.c_uint32, C.c_uint32, _dp, _dp]
+        L.orc_nearest.restype = C.c_uint32
+        L.orc_rrt_solve_many.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, C.c_int,
+                                         C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+class Rng:
+    """ChaCha12 stream keyed (seed, stream) with rand 0.9's bool / f64-range transforms."""
+
+    def __init__(self, seed, stream):
+        self._buf = C.create_string_buffer(512)
+        lib().orc_rng_seed(self._buf, seed, stream)
+
+    def next_u64(self):
+        return lib().orc_rng_next_u64(self._buf)
+
+    def random_bool(self, p):
+        return bool(lib().orc_random_bool(self._buf, p))
+
+    def random_range(self, lo, hi):
+        return lib().orc_random_range(self._buf, lo, hi)
+
+
+def chacha_block(key8, counter, stream, rounds):
+    k = (C.c_uint32 * 8)(*key8)
+    out = (C.c_uint32 * 16)()
+    lib().orc_chacha_block(k, counter, stream, rounds, out)
+    return list(out)
+
+
+def distance(a, b):
+    a, pa = _d(a)
+    b, pb = _d(b)
+    return lib().orc_distance(pa, pb, a.size)
+
+
+def interpolate(a, b, t):
+    a, pa = _d(a)
+    b, pb = _d(b)
+    out = np.empty_like(a)
+    lib().orc_interpolate(pa, pb, t, out.ctypes.data_as(_dp), a.size)
+    return out
+
+
+def maximum_extent(bounds):
+    b, pb = _d(np.asarray(bounds, dtype=np.float64).reshape(-1))
+    return lib().orc_maximum_extent(pb, b.size // 2)
+
+
+def num_steps(dist, lvsl):
+    return lib().orc_num_steps(dist, lvsl)
+
+
+def nearest(nodes_aos, q):
+    n, pn = _d(nodes_aos)
+    qq, pq = _d(q)
+    md = C.c_double()
+    idx = lib().orc_nearest(pn, n.shape[0], n.shape[1], pq, C.byref(md))
+    return idx, md.value
+
+
+class OracleRRT:
+    """One planner instance = one oxmpl RRT<RealVectorState, RealVectorStateSpace, BallGoal>."""
+
+    def __init__(self, dim, bounds, max_distance, goal_bias, lvs_fraction=0.05, max_nodes=10000,
+                 stop_at_goal=True, seed=0, problem_id=0):
+        self.dim = dim
+        b, pb = _d(np.asarray(bounds, dtype=np.float64).reshape(-1))
+        st = C.c_int()
+        self.h = lib().orc_rrt_new(dim, pb, max_distance, goal_bias, lvs_fraction, max_nodes,
+                                   int(stop_at_goal), seed, problem_id, C.byref(st))
+        self.create_status = st.value
+        if not self.h:
+            raise ValueError("orc_rrt_new failed with status %d" % st.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_rrt_free(self.h)
+            self.h = None
+
+    def set_spheres(self, centres, radii):
+        c, pc = _d(np.asarray(centres, dtype=np.float64).reshape(-1, self.dim))
+        r, pr = _d(radii)
+        lib().orc_rrt_set_spheres(self.h, pc, pr, r.size)
+
+    def set_boxes(self, lo, hi):
+        l, pl = _d(np.asarray(lo, dtype=np.float64).reshape(-1, self.dim))
+        h, ph = _d(np.asarray(hi, dtype=np.float64).reshape(-1, self.dim))
+        lib().orc_rrt_set_boxes(self.h, pl, ph, l.shape[0])
+
+    def setup(self, start, goal_centre, goal_radius):
+        s, ps = _d(start)
+        g, pg = _d(goal_centre)
+        return lib().orc_rrt_setup(self.h, ps, pg, goal_radius)
+
+    def solve(self, max_iterations, freeze=False, timeout_s=float("inf")):
+        return lib().orc_rrt_solve(self.h, max_iterations, int(freeze), timeout_s)
+
+    @property
+    def num_nodes(self):
+        return lib().orc_rrt_num_nodes(self.h)
+
+    @property
+    def iterations(self):
+        return lib().orc_rrt_iterations(self.h)
+
+    @property
+    def checksum(self):
+        return lib().orc_rrt_checksum(self.h)
+
+    @property
+    def accepted(self):
+        return lib().orc_rrt_accepted(self.h)
+
+    @property
+    def goal_node(self):
+        return lib().orc_rrt_goal_node(self.h)
+
+    @property
+    def stop_reason(self):
+        return lib().orc_rrt_stop_reason(self.h)
+
+    def tree(self):
+        n = self.num_nodes
+        states = np.empty((n, self.dim), dtype=np.float64)
+        parents = np.empty(n, dtype=np.int32)
+        lib().orc_rrt_get_tree(self.h, states.ctypes.data_as(_dp),
+                               parents.ctypes.data_as(C.POINTER(C.c_int32)))
+        return states, parents
+
+    def path(self):
+        cap = self.num_nodes
+        out = np.empty((cap, self.dim), dtype=np.float64)
+        ln = lib().orc_rrt_get_path(self.h, out.ctypes.data_as(_dp), cap)
+        return out[:ln].copy()
+
+    def check_motion(self, a, b):
+        a, pa = _d(a)
+        b, pb = _d(b)
+        return bool(lib().orc_rrt_check_motion(self.h, pa, pb))
+
+    def is_valid(self, p):
+        p, pp = _d(p)
+        return bool(lib().orc_rrt_is_valid(self.h, pp))
+
+
+def solve_many(planners, max_iterations, freeze=False, threads=1):
+    arr = (C.c_void_p * len(planners))(*[p.h for p in planners])
+    return lib().orc_rrt_solve_many(arr, len(planners), max_iterations, int(freeze), threads)
