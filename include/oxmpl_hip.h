@@ -1,0 +1,173 @@
+/*
+ * oxmpl_hip.h -- C ABI of liboxmpl_hip.so: the MI355X (gfx950) batched RRT hot path.
+ *
+ * The reference (rossng/oxmpl, Rust) has no C ABI; the boundary of this path is the
+ * trait `Planner<S, SP, G>` (oxmpl/src/base/planner.rs:26-60) over `StateSpace`
+ * (space.rs:78-145), `StateValidityChecker` (validity.rs:39-48) and `Goal*`
+ * (goal.rs:12-41).  The entry points below are what a Rust `extern "C"` block (or
+ * cgo / ctypes) binds to put the HIP path behind those traits; each cites the
+ * reference item it replaces.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions: plain pointers + sizes, caller owns every host array (copied during
+ * the call), all states are f64, AoS `[n][dim]` on this boundary (SoA on the device).
+ * Every function returns an oxhip_status; nothing aborts or throws across the ABI.
+ * A handle is bound to one HIP device and one stream and is not re-entrant;
+ * different handles may be driven from different host threads / processes.
+ */
+#ifndef OXMPL_HIP_H
+#define OXMPL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OXHIP_ABI_VERSION 1
+#define OXHIP_MAX_DIM 8
+
+/* Status codes.  0-5 mirror `PlanningError` (oxmpl/src/base/error.rs:97-108) in
+ * declaration order (+1); 16-18 mirror the sampling/space errors the reference
+ * would panic on via unwrap() (rrt.rs:180,183; real_vector_state_space.rs:239-244,
+ * 78-83); 32+ are HIP/runtime conditions that have no reference counterpart. */
+typedef enum oxhip_status {
+    OXHIP_OK = 0,                       /* Ok(Path) / success */
+    OXHIP_ERR_TIMEOUT = 1,              /* PlanningError::Timeout            rrt.rs:172-174 */
+    OXHIP_ERR_NO_SOLUTION_FOUND = 2,    /* PlanningError::NoSolutionFound    rrt.rs:226 (iteration / node cap) */
+    OXHIP_ERR_PLANNER_UNINITIALISED = 3,/* PlanningError::PlannerUninitialised rrt.rs:160-163 */
+    OXHIP_ERR_INVALID_START_STATE = 4,  /* PlanningError::InvalidStartState  (unused by RRT, kept for parity of the enum) */
+    OXHIP_ERR_UNSAMPLED_STATE_SPACE = 5,/* PlanningError::UnsampledStateSpace (PRM only) */
+    OXHIP_ERR_BAD_ARG = 16,             /* null pointer, dim out of range, goal_bias outside [0,1], ... */
+    OXHIP_ERR_UNBOUNDED = 17,           /* StateSamplingError::UnboundedDimension  rvss.rs:239-241 */
+    OXHIP_ERR_ZERO_VOLUME = 18,         /* StateSamplingError::ZeroVolume / StateSpaceError::InvalidBound */
+    OXHIP_ERR_CAPACITY = 19,            /* caller buffer too small; required length is still written */
+    OXHIP_ERR_HIP = 32,                 /* a HIP runtime call failed; see oxhip_last_error_string() */
+    OXHIP_ERR_NO_DEVICE = 33            /* no gfx950 device visible -- there is NO CPU fallback */
+} oxhip_status;
+
+/* why a problem stopped (per-problem, next to its status) */
+typedef enum oxhip_stop_reason {
+    OXHIP_STOP_NONE = -1,
+    OXHIP_STOP_GOAL = 0,        /* goal.is_satisfied(q_new) with stop_at_goal      rrt.rs:220-223 */
+    OXHIP_STOP_ITERATIONS = 1,  /* iteration budget of this solve call exhausted */
+    OXHIP_STOP_NODES = 2,       /* tree reached max_nodes */
+    OXHIP_STOP_TIMEOUT = 3      /* wall-clock timeout between kernel chunks */
+} oxhip_stop_reason;
+
+typedef enum oxhip_kernel_kind {
+    OXHIP_KERNEL_AUTO = 0,      /* resident when the tree fits the register file, else streaming */
+    OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
+    OXHIP_KERNEL_RESIDENT = 2   /* tree held in the workgroup's vector registers */
+} oxhip_kernel_kind;
+
+/* RRT::new(max_distance, goal_bias) (rrt.rs:75-83) + RealVectorStateSpace::new(dim, bounds)
+ * (real_vector_state_space.rs:65-100) + the termination the reference lacks (rrt.rs:226). */
+typedef struct oxhip_rrt_config {
+    uint32_t struct_size;               /* = sizeof(oxhip_rrt_config) */
+    uint32_t dim;                       /* RealVectorStateSpace::dimension, 1..OXHIP_MAX_DIM */
+    double   bounds[2 * OXHIP_MAX_DIM]; /* (lo,hi) pairs, real_vector_state_space.rs:19 */
+    double   max_distance;              /* RRT::max_distance  rrt.rs:55 */
+    double   goal_bias;                 /* RRT::goal_bias     rrt.rs:57, must be in [0,1] */
+    double   lvs_fraction;              /* longest_valid_segment_fraction, default 0.05 (rvss.rs:98);
+                                           clamped like set_longest_valid_segment_fraction (rvss.rs:121-129) */
+    uint32_t n_problems;                /* independent planner instances in this batch */
+    uint32_t max_nodes;                 /* tree capacity per problem (build-defined node cap) */
+    uint32_t stop_at_goal;              /* 1: stop a problem at its first goal node (reference behaviour) */
+    uint32_t kernel;                    /* oxhip_kernel_kind */
+    uint64_t seed;                      /* RNG key: ChaCha12 key = LE(seed)||0^24, stream id = first_problem_id + p */
+    uint64_t first_problem_id;          /* global id of problem 0 of this batch (problem-parallel sharding) */
+    int32_t  device;                    /* HIP device ordinal */
+    uint32_t reserved;
+} oxhip_rrt_config;
+
+typedef struct oxhip_rrt_batch oxhip_rrt_batch;
+
+/* ---- library ---- */
+int32_t     oxhip_abi_version(void);
+const char* oxhip_status_string(int32_t status);
+const char* oxhip_last_error_string(void);              /* thread-local detail of the last OXHIP_ERR_* */
+int32_t     oxhip_device_count(int32_t* count);         /* OXHIP_ERR_NO_DEVICE when none */
+
+/* ---- batched planner: replaces RRT::new / Planner::setup / Planner::solve ---- */
+
+/* RRT::new + RealVectorStateSpace::new for n_problems instances; allocates device trees. */
+int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** out);
+int32_t oxhip_rrt_batch_destroy(oxhip_rrt_batch* b);
+
+/* Device-describable StateValidityChecker (validity.rs:39-48), shared by all problems:
+ * a state is valid iff for every sphere distance(centre, p) > radius  (strict, the shape of
+ * README.md:147-150) and it is inside no box: NOT(lo_k <= p_k <= hi_k for all k)
+ * (the wall of oxmpl/tests/rrt_rvss_tests.rs:24-36).  Replaces any earlier field. */
+int32_t oxhip_rrt_batch_set_spheres(oxhip_rrt_batch* b, const double* centres /*[n][dim]*/,
+                                    const double* radii /*[n]*/, uint32_t n);
+int32_t oxhip_rrt_batch_set_boxes(oxhip_rrt_batch* b, const double* lo /*[n][dim]*/,
+                                  const double* hi /*[n][dim]*/, uint32_t n);
+
+/* Planner::setup (rrt.rs:140-156) for every problem: clears the tree, pushes start_states[0]
+ * (validity of the start is NOT checked, as in the reference), resets counters and the RNG
+ * stream.  Goal = ball: is_satisfied(s) = distance(s, centre) <= radius
+ * (rrt_rvss_tests.rs:45-49); sample_goal() = centre and draws nothing (README.md:160-162). */
+int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts /*[P][dim]*/,
+                              const double* goal_centres /*[P][dim]*/, const double* goal_radii /*[P]*/);
+
+/* Planner::solve (rrt.rs:158-227).  Runs every unfinished problem for at most max_iterations
+ * further iterations (one iteration = one pass of rrt.rs:170-225).  timeout_s bounds wall time
+ * (checked between kernel chunks; <= 0 or inf = none).  freeze != 0 suppresses inserts
+ * ("steady" measurement mode: every nearest-neighbour scan sees the same tree).
+ * status_out[P] (may be NULL): OXHIP_OK if the problem has a goal node, else
+ * OXHIP_ERR_NO_SOLUTION_FOUND / OXHIP_ERR_TIMEOUT.  Calling solve again continues the same
+ * trees and RNG streams (the reference's tree also persists across solve calls). */
+int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, double timeout_s,
+                              uint32_t freeze, int32_t* status_out);
+
+/* per-problem counters (any pointer may be NULL) */
+int32_t oxhip_rrt_batch_get_counts(oxhip_rrt_batch* b, uint64_t* iterations /*[P]*/,
+                                   uint32_t* nodes /*[P]*/, uint64_t* accepted /*[P]*/,
+                                   uint64_t* checksum /*[P]*/, int32_t* goal_node /*[P]*/,
+                                   int32_t* stop_reason /*[P]*/);
+
+/* RRT::tree of problem p (rrt.rs:61): states AoS [n][dim] and parent indices (-1 = None). */
+int32_t oxhip_rrt_batch_get_tree(oxhip_rrt_batch* b, uint32_t problem, double* states,
+                                 int32_t* parents, uint32_t cap_nodes, uint32_t* n_nodes);
+
+/* reconstruct_path (rrt.rs:118-128) from the first goal node; len = 0 when unsolved. */
+int32_t oxhip_rrt_batch_get_path(oxhip_rrt_batch* b, uint32_t problem, double* states,
+                                 uint32_t cap_states, uint32_t* len);
+
+/* HIP-event time (ms) of the kernels of the last solve call, their launch count, and which
+ * kernel ran (oxhip_kernel_kind). */
+int32_t oxhip_rrt_batch_last_timing(oxhip_rrt_batch* b, double* kernel_ms, uint32_t* launches,
+                                    uint32_t* kernel_kind);
+
+/* ---- stand-alone batched primitives (same device functions as the planner kernels) ---- */
+
+/* nearest-neighbour argmin of rrt.rs:187-196 for Q independent (tree, query) pairs:
+ * nodes AoS [sum n_nodes][dim] concatenated, offsets via n_nodes[Q]; queries [Q][dim];
+ * out: index (lowest index among post-sqrt ties) and min_dist = distance(nodes[idx], q). */
+int32_t oxhip_nn_argmin_batch(int32_t device, uint32_t dim, const double* nodes,
+                              const uint32_t* n_nodes, uint32_t n_queries, const double* queries,
+                              uint32_t* out_index, double* out_min_dist);
+
+/* RealVectorStateSpace::distance (rvss.rs:137-155) and ::interpolate (rvss.rs:161-186), n pairs */
+int32_t oxhip_distance_batch(int32_t device, uint32_t dim, const double* a, const double* b,
+                             uint32_t n, double* out);
+int32_t oxhip_interpolate_batch(int32_t device, uint32_t dim, const double* from, const double* to,
+                                const double* t, uint32_t n, double* out);
+
+/* StateValidityChecker::is_valid for n states and RRT::check_motion (rrt.rs:90-116) for n
+ * (from,to) pairs against the batch's current sphere/box field and space resolution. */
+int32_t oxhip_rrt_batch_is_valid(oxhip_rrt_batch* b, const double* states, uint32_t n, uint8_t* out);
+int32_t oxhip_rrt_batch_check_motion(oxhip_rrt_batch* b, const double* from, const double* to,
+                                     uint32_t n, uint8_t* out);
+
+/* device arithmetic self-test hooks: out[i] = op(a[i], b[i]) computed on the GPU.
+ * op: 0 sqrt(a), 1 a/b, 2 ceil(a), 3 a + (b - a) * t (t = c[i], unfused), 4 (a-b)*(a-b) */
+int32_t oxhip_f64_op_batch(int32_t device, uint32_t op, const double* a, const double* b,
+                           const double* c, uint32_t n, double* out);
+/* device RNG self-test: the first n u64 words of the (seed, stream) ChaCha12 stream */
+int32_t oxhip_rng_u64_batch(int32_t device, uint64_t seed, uint64_t stream, uint32_t n, uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OXMPL_HIP_H */

@@ -1,0 +1,625 @@
+// oxhip_api.hip -- implementation of the C ABI declared in include/oxmpl_hip.h.
+//
+// Host side of the drop-in boundary: validates what the reference would reject or panic on
+// (real_vector_state_space.rs:69-93,239-244; rand's Bernoulli::new), precomputes the values
+// the reference recomputes per call (extent, lvsl: rvss.rs:103-118,251-253), owns the device
+// buffers and launches the kernels.  There is no CPU fallback: without a HIP device every
+// entry point that computes returns OXHIP_ERR_NO_DEVICE.
+#include "../../include/oxmpl_hip.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "oxhip_internal.hpp"
+#include "rrt_device.hpp"
+
+using namespace oxhip;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(OXHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+int32_t select_device(int32_t device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(OXHIP_ERR_NO_DEVICE, "no HIP device visible (liboxmpl_hip has no CPU fallback)");
+    if (device < 0 || device >= count) return fail(OXHIP_ERR_BAD_ARG, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    return OXHIP_OK;
+}
+
+// largest x with sqrt(x) <= r under correctly rounded binary64 sqrt, so that
+//   sqrt(d2) >  r  <=>  d2 >  T      (sphere validity, strict)
+//   sqrt(d2) <= r  <=>  d2 <= T      (ball goal)
+// hold exactly and the kernels need no sqrt per obstacle.  r < 0 -> -1, NaN -> NaN.
+double sqrt_le_threshold(double r) {
+    if (std::isnan(r)) return r;
+    if (r < 0.0) return -1.0;
+    if (std::isinf(r)) return r;
+    double x = r * r;
+    if (std::isinf(x)) x = std::numeric_limits<double>::max();
+    while (std::sqrt(x) > r) x = std::nextafter(x, -1.0);
+    for (;;) {
+        double y = std::nextafter(x, std::numeric_limits<double>::infinity());
+        if (std::isinf(y) || std::sqrt(y) > r) break;
+        x = y;
+    }
+    return x;
+}
+
+// rand 0.9 Bernoulli::new
+uint64_t bernoulli_p_int(double p) {
+    if (p == 1.0) return ~0ull;
+    double v = p * 18446744073709551616.0;
+    if (!(v > 0.0)) return 0;
+    if (v >= 18446744073709551616.0) return ~0ull;
+    return (uint64_t)v;
+}
+
+constexpr double kMaxMagnitude = 1e150;  // keeps every squared difference finite
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t count) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void**)&p, count * sizeof(T));
+    }
+};
+
+}  // namespace
+
+namespace {
+struct TmpStream {
+    hipStream_t s = nullptr;
+    ~TmpStream() { if (s) (void)hipStreamDestroy(s); }
+};
+template <typename T>
+int32_t to_device(DevBuf<T>& buf, const T* host, size_t n, hipStream_t s) {
+    HIP_TRY(buf.alloc(n));
+    if (n) HIP_TRY(hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return OXHIP_OK;
+}
+template <typename T>
+int32_t to_host(T* host, const DevBuf<T>& buf, size_t n, hipStream_t s) {
+    if (n) HIP_TRY(hipMemcpyAsync(host, buf.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return OXHIP_OK;
+}
+}  // namespace
+
+struct oxhip_rrt_batch {
+    oxhip_rrt_config cfg{};
+    DevParams dp{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevBuf<double> tree, goal_c, goal_thr, sph_c, sph_thr, box_lo, box_hi;
+    DevBuf<int32_t> parent;
+    DevBuf<ProblemState> state;
+    std::vector<double> starts;  // host copy, [P][dim]
+    bool is_setup = false;
+    double last_kernel_ms = 0.0;
+    uint32_t last_launches = 0;
+    uint32_t kernel_kind = OXHIP_KERNEL_STREAM;
+};
+
+extern "C" {
+
+int32_t oxhip_abi_version(void) { return OXHIP_ABI_VERSION; }
+
+const char* oxhip_status_string(int32_t s) {
+    switch (s) {
+        case OXHIP_OK: return "ok";
+        case OXHIP_ERR_TIMEOUT: return "Planner timed out.";  // wording of error.rs Display
+        case OXHIP_ERR_NO_SOLUTION_FOUND: return "No solution found.";
+        case OXHIP_ERR_PLANNER_UNINITIALISED: return "Planner was not set up before calling solve.";
+        case OXHIP_ERR_INVALID_START_STATE: return "Start state is invalid.";
+        case OXHIP_ERR_UNSAMPLED_STATE_SPACE: return "State space has not been sampled.";
+        case OXHIP_ERR_BAD_ARG: return "bad argument";
+        case OXHIP_ERR_UNBOUNDED: return "Cannot sample uniformly because a dimension is unbounded.";
+        case OXHIP_ERR_ZERO_VOLUME: return "Cannot sample from a region with zero volume.";
+        case OXHIP_ERR_CAPACITY: return "caller buffer too small";
+        case OXHIP_ERR_HIP: return "HIP runtime error";
+        case OXHIP_ERR_NO_DEVICE: return "no HIP device (no CPU fallback exists)";
+        default: return "unknown status";
+    }
+}
+
+const char* oxhip_last_error_string(void) { return g_last_error.c_str(); }
+
+int32_t oxhip_device_count(int32_t* count) {
+    if (!count) return fail(OXHIP_ERR_BAD_ARG, "count is null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    *count = (e == hipSuccess) ? c : 0;
+    if (e != hipSuccess || c <= 0) return fail(OXHIP_ERR_NO_DEVICE, "no HIP device visible");
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** out) {
+    if (!cfg || !out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(oxhip_rrt_config)) return fail(OXHIP_ERR_BAD_ARG, "struct_size mismatch");
+    if (cfg->dim == 0 || cfg->dim > OXHIP_MAX_DIM) return fail(OXHIP_ERR_BAD_ARG, "dim must be in 1..8");
+    if (cfg->n_problems == 0 || cfg->max_nodes == 0) return fail(OXHIP_ERR_BAD_ARG, "n_problems and max_nodes must be > 0");
+    if (cfg->max_nodes > (1u << 30)) return fail(OXHIP_ERR_BAD_ARG, "max_nodes too large");
+    if (!(cfg->goal_bias >= 0.0 && cfg->goal_bias <= 1.0))
+        return fail(OXHIP_ERR_BAD_ARG, "goal_bias outside [0,1] (rand Bernoulli::new would fail)");
+    if (!(cfg->max_distance > 0.0) || !std::isfinite(cfg->max_distance))
+        return fail(OXHIP_ERR_BAD_ARG, "max_distance must be finite and > 0");
+    if (cfg->kernel > OXHIP_KERNEL_RESIDENT) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
+    for (uint32_t k = 0; k < cfg->dim; ++k) {
+        double lo = cfg->bounds[2 * k], hi = cfg->bounds[2 * k + 1];
+        if (!std::isfinite(lo) || !std::isfinite(hi))  // real_vector_state_space.rs:239-241
+            return fail(OXHIP_ERR_UNBOUNDED, "dimension " + std::to_string(k) + " is unbounded");
+        if (lo >= hi) return fail(OXHIP_ERR_ZERO_VOLUME, "lower bound >= upper bound");  // rvss.rs:78-83,242-244
+        if (std::fabs(lo) > kMaxMagnitude || std::fabs(hi) > kMaxMagnitude)
+            return fail(OXHIP_ERR_BAD_ARG, "bounds beyond 1e150 would overflow squared distances");
+    }
+    // set_longest_valid_segment_fraction clamp (rvss.rs:121-129)
+    double fraction = cfg->lvs_fraction;
+    if (fraction > 0.0 && fraction <= 1.0) {} else if (fraction <= 0.0) fraction = 0.0; else fraction = 1.0;
+    // get_maximum_extent (rvss.rs:103-118): sequential sum of squared widths, sqrt
+    double acc = 0.0;
+    for (uint32_t k = 0; k < cfg->dim; ++k) {
+        double w = cfg->bounds[2 * k + 1] - cfg->bounds[2 * k];
+        double sq = w * w;
+        acc = acc + sq;
+    }
+    double extent = std::sqrt(acc);
+    double lvsl = extent * fraction;  // rvss.rs:251-253
+    double res = lvsl * 0.1;          // rrt.rs:97
+    if (!(res > 0.0)) return fail(OXHIP_ERR_BAD_ARG, "longest valid segment length is 0: check_motion would never terminate");
+    if (cfg->max_distance / res > 1e6) return fail(OXHIP_ERR_BAD_ARG, "more than 1e6 validity checks per edge");
+
+    int32_t st = select_device(cfg->device);
+    if (st != OXHIP_OK) return st;
+
+    auto* b = new oxhip_rrt_batch();
+    b->cfg = *cfg;
+    b->cfg.lvs_fraction = fraction;
+    const uint32_t P = cfg->n_problems, dim = cfg->dim;
+    const uint32_t cap = ((cfg->max_nodes + 1023u) / 1024u) * 1024u;
+    DevParams& dp = b->dp;
+    dp.dim = dim; dp.n_problems = P; dp.cap = cap; dp.max_nodes = cfg->max_nodes;
+    for (uint32_t k = 0; k < dim; ++k) {
+        dp.lo[k] = cfg->bounds[2 * k];
+        dp.hi[k] = cfg->bounds[2 * k + 1];
+        dp.scale[k] = dp.hi[k] - dp.lo[k];
+    }
+    dp.max_distance = cfg->max_distance;
+    dp.res = res;
+    dp.p_int = bernoulli_p_int(cfg->goal_bias);
+    dp.seed = cfg->seed;
+    dp.first_problem_id = cfg->first_problem_id;
+    dp.stop_at_goal = cfg->stop_at_goal ? 1 : 0;
+
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    chk(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    chk(hipEventCreate(&b->ev0));
+    chk(hipEventCreate(&b->ev1));
+    chk(b->tree.alloc((size_t)P * dim * cap));
+    chk(b->parent.alloc((size_t)P * cap));
+    chk(b->state.alloc(P));
+    chk(b->goal_c.alloc((size_t)P * dim));
+    chk(b->goal_thr.alloc(P));
+    if (e != hipSuccess) {
+        std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e);
+        oxhip_rrt_batch_destroy(b);
+        return fail(OXHIP_ERR_HIP, msg);
+    }
+    dp.tree = b->tree.p; dp.parent = b->parent.p; dp.state = b->state.p;
+    dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p;
+
+    uint32_t kind = cfg->kernel;
+    if (kind == OXHIP_KERNEL_AUTO) kind = resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
+    if (kind == OXHIP_KERNEL_RESIDENT && !resident_supported(dim, cap)) {
+        oxhip_rrt_batch_destroy(b);
+        return fail(OXHIP_ERR_BAD_ARG, "resident kernel does not support this (dim, max_nodes)");
+    }
+    b->kernel_kind = kind;
+    *out = b;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_destroy(oxhip_rrt_batch* b) {
+    if (!b) return OXHIP_OK;
+    (void)hipSetDevice(b->cfg.device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+    return OXHIP_OK;
+}
+
+static int32_t upload(DevBuf<double>& buf, const std::vector<double>& host, hipStream_t s) {
+    HIP_TRY(buf.alloc(host.size()));
+    if (!host.empty()) {
+        HIP_TRY(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_set_spheres(oxhip_rrt_batch* b, const double* centres, const double* radii, uint32_t n) {
+    if (!b || (n && (!centres || !radii))) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    const uint32_t dim = b->cfg.dim;
+    std::vector<double> c((size_t)dim * n), thr(n);
+    for (uint32_t j = 0; j < n; ++j) {
+        for (uint32_t k = 0; k < dim; ++k) {
+            double v = centres[(size_t)j * dim + k];
+            if (!(std::fabs(v) <= kMaxMagnitude)) return fail(OXHIP_ERR_BAD_ARG, "sphere centre not finite / too large");
+            c[(size_t)k * n + j] = v;  // SoA [dim][n]
+        }
+        thr[j] = sqrt_le_threshold(radii[j]);
+    }
+    if ((st = upload(b->sph_c, c, b->stream)) != OXHIP_OK) return st;
+    if ((st = upload(b->sph_thr, thr, b->stream)) != OXHIP_OK) return st;
+    b->dp.n_spheres = n; b->dp.sph_c = b->sph_c.p; b->dp.sph_thr = b->sph_thr.p;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_set_boxes(oxhip_rrt_batch* b, const double* lo, const double* hi, uint32_t n) {
+    if (!b || (n && (!lo || !hi))) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    const uint32_t dim = b->cfg.dim;
+    std::vector<double> l((size_t)dim * n), h((size_t)dim * n);
+    for (uint32_t j = 0; j < n; ++j)
+        for (uint32_t k = 0; k < dim; ++k) {
+            l[(size_t)k * n + j] = lo[(size_t)j * dim + k];
+            h[(size_t)k * n + j] = hi[(size_t)j * dim + k];
+        }
+    if ((st = upload(b->box_lo, l, b->stream)) != OXHIP_OK) return st;
+    if ((st = upload(b->box_hi, h, b->stream)) != OXHIP_OK) return st;
+    b->dp.n_boxes = n; b->dp.box_lo = b->box_lo.p; b->dp.box_hi = b->box_hi.p;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const double* goal_centres,
+                              const double* goal_radii) {
+    if (!b || !starts || !goal_centres || !goal_radii) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    const uint32_t P = b->cfg.n_problems, dim = b->cfg.dim, cap = b->dp.cap;
+    for (size_t i = 0; i < (size_t)P * dim; ++i)
+        if (!(std::fabs(starts[i]) <= kMaxMagnitude) || !(std::fabs(goal_centres[i]) <= kMaxMagnitude))
+            return fail(OXHIP_ERR_BAD_ARG, "start / goal centre not finite or beyond 1e150");
+    b->starts.assign(starts, starts + (size_t)P * dim);
+    std::vector<double> thr(P);
+    for (uint32_t p = 0; p < P; ++p) thr[p] = sqrt_le_threshold(goal_radii[p]);
+    std::vector<ProblemState> states(P);
+    for (auto& s : states) {
+        s = ProblemState{};
+        s.checksum = kFnvBasis;
+        s.n_nodes = 1;
+        s.goal_node = -1;
+        s.stop_reason = OXHIP_STOP_NONE;
+    }
+    std::vector<int32_t> root(1, -1);
+    HIP_TRY(hipMemcpyAsync(b->goal_c.p, goal_centres, (size_t)P * dim * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->goal_thr.p, thr.data(), P * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->state.p, states.data(), P * sizeof(ProblemState), hipMemcpyHostToDevice, b->stream));
+    // tree.clear(); tree.push(Node{start_states[0], None})   rrt.rs:147-155
+    // node 0 of coordinate k of problem p lives at tree[(p*dim + k)*cap]: strided 2-D copy
+    HIP_TRY(hipMemcpy2DAsync(b->tree.p, (size_t)cap * sizeof(double), starts, sizeof(double), sizeof(double),
+                             (size_t)P * dim, hipMemcpyHostToDevice, b->stream));
+    std::vector<int32_t> minus1(P, -1);
+    HIP_TRY(hipMemcpy2DAsync(b->parent.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
+                             sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->is_setup = true;
+    return OXHIP_OK;
+}
+
+static int32_t read_states(oxhip_rrt_batch* b, std::vector<ProblemState>& states) {
+    states.resize(b->cfg.n_problems);
+    HIP_TRY(hipMemcpyAsync(states.data(), b->state.p, states.size() * sizeof(ProblemState), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, double timeout_s, uint32_t freeze,
+                              int32_t* status_out) {
+    if (!b) return fail(OXHIP_ERR_BAD_ARG, "null batch");
+    if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");  // rrt.rs:160-163
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    const bool has_timeout = timeout_s > 0.0 && std::isfinite(timeout_s);
+    const auto t0 = std::chrono::steady_clock::now();
+    // with a timeout the budget is cut into chunks so the host clock is consulted in between
+    const uint64_t chunk = has_timeout ? 2048 : max_iterations;
+    uint64_t remaining = max_iterations;
+    b->last_kernel_ms = 0.0;
+    b->last_launches = 0;
+    bool timed_out = false;
+    std::vector<ProblemState> states;
+    while (remaining > 0) {
+        uint64_t step = remaining < chunk ? remaining : chunk;
+        b->dp.budget = step;
+        b->dp.freeze = freeze ? 1 : 0;
+        HIP_TRY(hipEventRecord(b->ev0, b->stream));
+        if (b->kernel_kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
+        else launch_rrt_stream(b->dp, b->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b->ev1, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+        b->last_kernel_ms += ms;
+        b->last_launches++;
+        remaining -= step;
+        if (remaining == 0) break;
+        if ((st = read_states(b, states)) != OXHIP_OK) return st;
+        bool any_running = false;
+        for (auto& s : states) if (s.stop_reason == OXHIP_STOP_ITERATIONS) { any_running = true; break; }
+        if (!any_running) break;
+        if (has_timeout && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+            timed_out = true;  // rrt.rs:172-174
+            break;
+        }
+    }
+    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    if (timed_out) {
+        for (auto& s : states) if (s.stop_reason == OXHIP_STOP_ITERATIONS) s.stop_reason = OXHIP_STOP_TIMEOUT;
+        HIP_TRY(hipMemcpyAsync(b->state.p, states.data(), states.size() * sizeof(ProblemState), hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    if (status_out)
+        for (uint32_t p = 0; p < b->cfg.n_problems; ++p) {
+            const ProblemState& s = states[p];
+            status_out[p] = s.goal_node >= 0 ? OXHIP_OK
+                          : (s.stop_reason == OXHIP_STOP_TIMEOUT ? OXHIP_ERR_TIMEOUT : OXHIP_ERR_NO_SOLUTION_FOUND);
+        }
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_get_counts(oxhip_rrt_batch* b, uint64_t* iterations, uint32_t* nodes, uint64_t* accepted,
+                                   uint64_t* checksum, int32_t* goal_node, int32_t* stop_reason) {
+    if (!b) return fail(OXHIP_ERR_BAD_ARG, "null batch");
+    if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    std::vector<ProblemState> states;
+    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    for (uint32_t p = 0; p < b->cfg.n_problems; ++p) {
+        if (iterations) iterations[p] = states[p].iterations;
+        if (nodes) nodes[p] = states[p].n_nodes;
+        if (accepted) accepted[p] = states[p].accepted;
+        if (checksum) checksum[p] = states[p].checksum;
+        if (goal_node) goal_node[p] = states[p].goal_node;
+        if (stop_reason) stop_reason[p] = states[p].stop_reason;
+    }
+    return OXHIP_OK;
+}
+
+static int32_t fetch_tree(oxhip_rrt_batch* b, uint32_t problem, uint32_t n, std::vector<double>& soa,
+                          std::vector<int32_t>& parents) {
+    const uint32_t dim = b->cfg.dim, cap = b->dp.cap;
+    soa.resize((size_t)dim * n);
+    parents.resize(n);
+    // [dim][n] out of [dim][cap]
+    HIP_TRY(hipMemcpy2DAsync(soa.data(), (size_t)n * sizeof(double), b->tree.p + (size_t)problem * dim * cap,
+                             (size_t)cap * sizeof(double), (size_t)n * sizeof(double), dim, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(parents.data(), b->parent.p + (size_t)problem * cap, (size_t)n * sizeof(int32_t),
+                           hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_get_tree(oxhip_rrt_batch* b, uint32_t problem, double* states_out, int32_t* parents_out,
+                                 uint32_t cap_nodes, uint32_t* n_nodes) {
+    if (!b || !n_nodes) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");
+    if (problem >= b->cfg.n_problems) return fail(OXHIP_ERR_BAD_ARG, "problem index out of range");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    std::vector<ProblemState> states;
+    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    const uint32_t n = states[problem].n_nodes, dim = b->cfg.dim;
+    *n_nodes = n;
+    if (n > cap_nodes || (!states_out && !parents_out)) return n > cap_nodes ? fail(OXHIP_ERR_CAPACITY, "tree buffer too small") : OXHIP_OK;
+    std::vector<double> soa;
+    std::vector<int32_t> par;
+    if ((st = fetch_tree(b, problem, n, soa, par)) != OXHIP_OK) return st;
+    if (states_out)
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t k = 0; k < dim; ++k) states_out[(size_t)i * dim + k] = soa[(size_t)k * n + i];
+    if (parents_out) std::memcpy(parents_out, par.data(), (size_t)n * sizeof(int32_t));
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_get_path(oxhip_rrt_batch* b, uint32_t problem, double* states_out, uint32_t cap_states,
+                                 uint32_t* len) {
+    if (!b || !len) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");
+    if (problem >= b->cfg.n_problems) return fail(OXHIP_ERR_BAD_ARG, "problem index out of range");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    std::vector<ProblemState> states;
+    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    *len = 0;
+    const int32_t goal = states[problem].goal_node;
+    if (goal < 0) return OXHIP_OK;
+    const uint32_t n = states[problem].n_nodes, dim = b->cfg.dim;
+    std::vector<double> soa;
+    std::vector<int32_t> par;
+    if ((st = fetch_tree(b, problem, n, soa, par)) != OXHIP_OK) return st;
+    // reconstruct_path (rrt.rs:118-128): follow parents from the goal node, reverse
+    std::vector<uint32_t> chain;
+    for (int64_t i = goal; i >= 0; i = par[(size_t)i]) {
+        chain.push_back((uint32_t)i);
+        if (chain.size() > n) return fail(OXHIP_ERR_HIP, "parent chain is cyclic (corrupt tree)");
+    }
+    *len = (uint32_t)chain.size();
+    if (chain.size() > cap_states || !states_out) return chain.size() > cap_states ? fail(OXHIP_ERR_CAPACITY, "path buffer too small") : OXHIP_OK;
+    for (size_t j = 0; j < chain.size(); ++j) {
+        uint32_t i = chain[chain.size() - 1 - j];
+        for (uint32_t k = 0; k < dim; ++k) states_out[j * dim + k] = soa[(size_t)k * n + i];
+    }
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_last_timing(oxhip_rrt_batch* b, double* kernel_ms, uint32_t* launches, uint32_t* kernel_kind) {
+    if (!b) return fail(OXHIP_ERR_BAD_ARG, "null batch");
+    if (kernel_ms) *kernel_ms = b->last_kernel_ms;
+    if (launches) *launches = b->last_launches;
+    if (kernel_kind) *kernel_kind = b->kernel_kind;
+    return OXHIP_OK;
+}
+
+// ------------------------------------------------------------------ stand-alone primitives
+
+#define OX_TRY(expr) do { int32_t s_ = (expr); if (s_ != OXHIP_OK) return s_; } while (0)
+
+int32_t oxhip_nn_argmin_batch(int32_t device, uint32_t dim, const double* nodes, const uint32_t* n_nodes,
+                              uint32_t n_queries, const double* queries, uint32_t* out_index, double* out_min_dist) {
+    if (!nodes || !n_nodes || !queries || !out_index || !out_min_dist) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (dim == 0 || dim > OXHIP_MAX_DIM) return fail(OXHIP_ERR_BAD_ARG, "dim must be in 1..8");
+    if (n_queries == 0) return OXHIP_OK;
+    OX_TRY(select_device(device));
+    std::vector<uint64_t> offsets(n_queries);
+    uint64_t total = 0;
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        if (n_nodes[q] == 0) return fail(OXHIP_ERR_BAD_ARG, "every tree needs at least its root (rrt.rs:188 reads tree[0])");
+        offsets[q] = total;
+        total += n_nodes[q];
+    }
+    TmpStream ts;
+    HIP_TRY(hipStreamCreate(&ts.s));
+    DevBuf<double> d_nodes, d_q, d_dist;
+    DevBuf<uint64_t> d_off;
+    DevBuf<uint32_t> d_n, d_idx;
+    OX_TRY(to_device(d_nodes, nodes, (size_t)total * dim, ts.s));
+    OX_TRY(to_device(d_q, queries, (size_t)n_queries * dim, ts.s));
+    OX_TRY(to_device(d_off, offsets.data(), n_queries, ts.s));
+    OX_TRY(to_device(d_n, n_nodes, n_queries, ts.s));
+    HIP_TRY(d_idx.alloc(n_queries));
+    HIP_TRY(d_dist.alloc(n_queries));
+    launch_nn_argmin(dim, d_nodes.p, d_off.p, d_n.p, n_queries, d_q.p, d_idx.p, d_dist.p, ts.s);
+    HIP_TRY(hipGetLastError());
+    OX_TRY(to_host(out_index, d_idx, n_queries, ts.s));
+    OX_TRY(to_host(out_min_dist, d_dist, n_queries, ts.s));
+    return OXHIP_OK;
+}
+
+int32_t oxhip_distance_batch(int32_t device, uint32_t dim, const double* a, const double* b, uint32_t n, double* out) {
+    if (!a || !b || !out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (dim == 0 || dim > OXHIP_MAX_DIM) return fail(OXHIP_ERR_BAD_ARG, "dim must be in 1..8");
+    if (n == 0) return OXHIP_OK;
+    OX_TRY(select_device(device));
+    TmpStream ts;
+    HIP_TRY(hipStreamCreate(&ts.s));
+    DevBuf<double> da, db, dout;
+    OX_TRY(to_device(da, a, (size_t)n * dim, ts.s));
+    OX_TRY(to_device(db, b, (size_t)n * dim, ts.s));
+    HIP_TRY(dout.alloc(n));
+    launch_distance(dim, da.p, db.p, n, dout.p, ts.s);
+    HIP_TRY(hipGetLastError());
+    return to_host(out, dout, n, ts.s);
+}
+
+int32_t oxhip_interpolate_batch(int32_t device, uint32_t dim, const double* from, const double* to, const double* t,
+                                uint32_t n, double* out) {
+    if (!from || !to || !t || !out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (dim == 0 || dim > OXHIP_MAX_DIM) return fail(OXHIP_ERR_BAD_ARG, "dim must be in 1..8");
+    if (n == 0) return OXHIP_OK;
+    OX_TRY(select_device(device));
+    TmpStream ts;
+    HIP_TRY(hipStreamCreate(&ts.s));
+    DevBuf<double> da, db, dt, dout;
+    OX_TRY(to_device(da, from, (size_t)n * dim, ts.s));
+    OX_TRY(to_device(db, to, (size_t)n * dim, ts.s));
+    OX_TRY(to_device(dt, t, n, ts.s));
+    HIP_TRY(dout.alloc((size_t)n * dim));
+    launch_interpolate(dim, da.p, db.p, dt.p, n, dout.p, ts.s);
+    HIP_TRY(hipGetLastError());
+    return to_host(out, dout, (size_t)n * dim, ts.s);
+}
+
+int32_t oxhip_rrt_batch_is_valid(oxhip_rrt_batch* b, const double* states, uint32_t n, uint8_t* out) {
+    if (!b || !states || !out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (n == 0) return OXHIP_OK;
+    OX_TRY(select_device(b->cfg.device));
+    DevBuf<double> ds;
+    DevBuf<uint8_t> dout;
+    OX_TRY(to_device(ds, states, (size_t)n * b->cfg.dim, b->stream));
+    HIP_TRY(dout.alloc(n));
+    launch_is_valid(b->dp, ds.p, n, dout.p, b->stream);
+    HIP_TRY(hipGetLastError());
+    return to_host(out, dout, n, b->stream);
+}
+
+int32_t oxhip_rrt_batch_check_motion(oxhip_rrt_batch* b, const double* from, const double* to, uint32_t n, uint8_t* out) {
+    if (!b || !from || !to || !out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (n == 0) return OXHIP_OK;
+    OX_TRY(select_device(b->cfg.device));
+    DevBuf<double> da, db;
+    DevBuf<uint8_t> dout;
+    OX_TRY(to_device(da, from, (size_t)n * b->cfg.dim, b->stream));
+    OX_TRY(to_device(db, to, (size_t)n * b->cfg.dim, b->stream));
+    HIP_TRY(dout.alloc(n));
+    launch_check_motion(b->dp, da.p, db.p, n, dout.p, b->stream);
+    HIP_TRY(hipGetLastError());
+    return to_host(out, dout, n, b->stream);
+}
+
+int32_t oxhip_f64_op_batch(int32_t device, uint32_t op, const double* a, const double* b, const double* c, uint32_t n,
+                           double* out) {
+    if (!a || !out || op > 4) return fail(OXHIP_ERR_BAD_ARG, "bad argument");
+    if ((op == 1 || op == 3 || op == 4) && !b) return fail(OXHIP_ERR_BAD_ARG, "operand b required");
+    if (op == 3 && !c) return fail(OXHIP_ERR_BAD_ARG, "operand c required");
+    if (n == 0) return OXHIP_OK;
+    OX_TRY(select_device(device));
+    TmpStream ts;
+    HIP_TRY(hipStreamCreate(&ts.s));
+    DevBuf<double> da, db, dc, dout;
+    OX_TRY(to_device(da, a, n, ts.s));
+    if (b) OX_TRY(to_device(db, b, n, ts.s));
+    if (c) OX_TRY(to_device(dc, c, n, ts.s));
+    HIP_TRY(dout.alloc(n));
+    launch_f64_op(op, da.p, db.p, dc.p, n, dout.p, ts.s);
+    HIP_TRY(hipGetLastError());
+    return to_host(out, dout, n, ts.s);
+}
+
+int32_t oxhip_rng_u64_batch(int32_t device, uint64_t seed, uint64_t stream, uint32_t n, uint64_t* out) {
+    if (!out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (n == 0) return OXHIP_OK;
+    OX_TRY(select_device(device));
+    TmpStream ts;
+    HIP_TRY(hipStreamCreate(&ts.s));
+    DevBuf<uint64_t> dout;
+    HIP_TRY(dout.alloc(n));
+    launch_rng_u64(seed, stream, n, dout.p, ts.s);
+    HIP_TRY(hipGetLastError());
+    return to_host(out, dout, n, ts.s);
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// rrt_device.hpp -- device functions shared by the RRT kernels (gfx950, wave64).
+//
+// Every function restates one piece of the reference's hot path in IEEE binary64 with the
+// reference's evaluation order; the translation unit is built with -ffp-contract=off so
+// that `from + (to - from) * t` keeps its three roundings (the reference, Rust, never fuses).
+//
+// Reference lines (relative to /root/reference):
+//   distance      oxmpl/src/base/spaces/real_vector_state_space.rs:137-155
+//   interpolate   oxmpl/src/base/spaces/real_vector_state_space.rs:161-186
+//   sample        oxmpl/src/base/spaces/real_vector_state_space.rs:233-249, rrt.rs:177-184
+//   nearest       oxmpl/src/geometric/planners/rrt.rs:187-196
+//   steer         oxmpl/src/geometric/planners/rrt.rs:199-208
+//   check_motion  oxmpl/src/geometric/planners/rrt.rs:90-116
+//   RNG           rand 0.9.1 random_bool / random_range(f64), rand_chacha 0.9.0 ChaCha12Rng
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace oxhip {
+
+constexpr int kMaxDim = 8;
+constexpr uint64_t kFnvPrime = 0x100000001B3ull;
+constexpr uint64_t kFnvBasis = 0xCBF29CE484222325ull;
+
+// per-problem planner state that persists in HBM between launches (resume / chunked solve)
+struct ProblemState {
+    uint64_t iterations;
+    uint64_t accepted;
+    uint64_t checksum;
+    uint64_t draws;       // u64 words consumed from the problem's ChaCha12 stream
+    uint32_t n_nodes;
+    int32_t goal_node;    // first node satisfying the goal, -1 = none
+    int32_t stop_reason;  // oxhip_stop_reason of the last launch
+    uint32_t pad;
+};
+
+// kernel arguments (by value)
+struct DevParams {
+    uint32_t dim, n_problems, cap, max_nodes;
+    double lo[kMaxDim], hi[kMaxDim], scale[kMaxDim];  // scale = hi - lo (random_range)
+    double max_distance;
+    double res;          // get_longest_valid_segment_length() * 0.1   (rrt.rs:97)
+    uint64_t p_int;      // Bernoulli::new(goal_bias)
+    uint64_t seed, first_problem_id;
+    uint64_t budget;     // iterations this launch may run per problem
+    uint32_t stop_at_goal, freeze;
+    uint32_t n_spheres, n_boxes;
+    const double* sph_c;    // [dim][n_spheres]
+    const double* sph_thr;  // [n_spheres]  valid iff d2 > thr  (== sqrt(d2) > radius, exactly)
+    const double* box_lo;   // [dim][n_boxes]
+    const double* box_hi;   // [dim][n_boxes]
+    double* tree;           // [P][dim][cap]  SoA per problem
+    int32_t* parent;        // [P][cap]
+    ProblemState* state;    // [P]
+    const double* goal_c;   // [P][dim]
+    const double* goal_thr; // [P]  satisfied iff d2 <= thr (== sqrt(d2) <= radius, exactly)
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double unid(double v) { return __longlong_as_double((long long)uni64((uint64_t)__double_as_longlong(v))); }
+
+// ------------------------------------------------------------------ ChaCha12 (rand_chacha)
+__device__ __forceinline__ uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+
+#define OXHIP_QR(a, b, c, d)               \
+    a += b; d ^= a; d = rotl32(d, 16);     \
+    c += d; b ^= c; b = rotl32(b, 12);     \
+    a += b; d ^= a; d = rotl32(d, 8);      \
+    c += d; b ^= c; b = rotl32(b, 7);
+
+// one 16-word block; key = LE(seed) || 0^24, 64-bit block counter, 64-bit stream id
+__device__ inline void chacha12_block(uint64_t seed, uint64_t counter, uint64_t stream, uint32_t out[16]) {
+    const uint32_t s0 = 0x61707865u, s1 = 0x3320646eu, s2 = 0x79622d32u, s3 = 0x6b206574u;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    const uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32);
+    const uint32_t t0 = (uint32_t)stream, t1 = (uint32_t)(stream >> 32);
+    uint32_t x0 = s0, x1 = s1, x2 = s2, x3 = s3, x4 = k0, x5 = k1, x6 = 0, x7 = 0;
+    uint32_t x8 = 0, x9 = 0, x10 = 0, x11 = 0, x12 = c0, x13 = c1, x14 = t0, x15 = t1;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        OXHIP_QR(x0, x4, x8, x12) OXHIP_QR(x1, x5, x9, x13) OXHIP_QR(x2, x6, x10, x14) OXHIP_QR(x3, x7, x11, x15)
+        OXHIP_QR(x0, x5, x10, x15) OXHIP_QR(x1, x6, x11, x12) OXHIP_QR(x2, x7, x8, x13) OXHIP_QR(x3, x4, x9, x14)
+    }
+    out[0] = x0 + s0; out[1] = x1 + s1; out[2] = x2 + s2; out[3] = x3 + s3;
+    out[4] = x4 + k0; out[5] = x5 + k1; out[6] = x6; out[7] = x7;
+    out[8] = x8; out[9] = x9; out[10] = x10; out[11] = x11;
+    out[12] = x12 + c0; out[13] = x13 + c1; out[14] = x14 + t0; out[15] = x15 + t1;
+}
+
+// Workgroup-shared window of 64 consecutive blocks (512 u64 words) of one problem's stream,
+// stored word-major ([word][block]) so the refill's 64 lanes write conflict-free.
+// All threads of the workgroup call next() in the same (uniform) sequence.
+struct RngWindow {
+    uint32_t (*buf)[64];   // LDS, [16][64]
+    uint64_t seed, stream;
+    uint64_t pos;          // absolute u64-word position in the stream (uniform)
+    uint64_t base_blk;     // first block held in buf (uniform)
+
+    __device__ __forceinline__ void init(uint32_t (*lds)[64], uint64_t seed_, uint64_t stream_, uint64_t pos_) {
+        buf = lds; seed = seed_; stream = stream_; pos = pos_;
+        base_blk = (pos_ >> 3) - 64;  // forces a refill on first use (modular arithmetic)
+    }
+    __device__ __forceinline__ uint64_t next() {
+        uint64_t blk = uni64(pos >> 3);
+        if (blk - base_blk >= 64) {  // workgroup-uniform
+            __syncthreads();         // everybody is done reading the old window
+            base_blk = blk;
+            if (threadIdx.x < 64) {
+                uint32_t o[16];
+                chacha12_block(seed, blk + threadIdx.x, stream, o);
+#pragma unroll
+                for (int w = 0; w < 16; ++w) buf[w][threadIdx.x] = o[w];
+            }
+            __syncthreads();
+        }
+        uint32_t l = uni((uint32_t)(blk - base_blk));
+        uint32_t w = uni((uint32_t)(pos & 7) * 2);
+        uint64_t lo = buf[w][l], hi = buf[w + 1][l];
+        pos = uni64(pos + 1);
+        return uni64((hi << 32) | lo);
+    }
+};
+
+// rrt.rs:177-184 + real_vector_state_space.rs:233-249 with rand 0.9's transforms.
+// Returns true when the goal was sampled (q = goal centre, no further draw).
+template <int D>
+__device__ __forceinline__ bool sample_state(RngWindow& rng, const DevParams& p, int dim, const double* goal_c,
+                                             double q[D]) {
+    bool goal;
+    if (p.p_int == ~0ull) goal = true;            // Bernoulli ALWAYS_TRUE: no draw
+    else goal = rng.next() < p.p_int;             // one u64
+    if (goal) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (k < dim) q[k] = goal_c[k];
+        return true;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if (k < dim) {
+            double res;
+            for (;;) {
+                uint64_t bits = (rng.next() >> 12) | 0x3FF0000000000000ull;
+                double v01 = __longlong_as_double((long long)bits) - 1.0;
+                res = v01 * p.scale[k];
+                res = res + p.lo[k];
+                if (res < p.hi[k]) break;     // else draw again (rand's sample_single loop)
+            }
+            q[k] = res;
+        }
+    }
+    return false;
+}
+
+// squared distance with the reference's summation order (sum starts at 0.0: 0.0 + x*x == x*x)
+template <int D>
+__device__ __forceinline__ double dist2(const double a[D], const double b[D], int dim) {
+    double d0 = a[0] - b[0];
+    double acc = d0 * d0;
+#pragma unroll
+    for (int k = 1; k < D; ++k) {
+        if (k < dim) {
+            double d = a[k] - b[k];
+            double sq = d * d;
+            acc = acc + sq;
+        }
+    }
+    return acc;
+}
+
+template <int D>
+__device__ __forceinline__ void lerp(const double from[D], const double to[D], double t, double out[D], int dim) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if (k < dim) {
+            double diff = to[k] - from[k];
+            double scaled = diff * t;
+            out[k] = from[k] + scaled;
+        }
+    }
+}
+
+// (dist / res).ceil() as usize, clamped to u32 (create() bounds the reachable step count)
+__device__ __forceinline__ uint32_t num_steps_u32(double dist, double res) {
+    double c = ceil(dist / res);
+    if (!(c > 0.0)) return 0;          // NaN / negative / zero: Rust's saturating cast gives 0
+    if (c >= 4294967295.0) return 0xFFFFFFFFu;
+    return (uint32_t)c;
+}
+
+// is obstacle j violated by state s?  j < n_spheres: sphere, else box j - n_spheres
+template <int D>
+__device__ __forceinline__ bool obstacle_hit(const DevParams& p, int dim, const double s[D], uint32_t j) {
+    if (j < p.n_spheres) {
+        double c[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (k < dim) c[k] = p.sph_c[(size_t)k * p.n_spheres + j];
+        double d2 = dist2<D>(c, s, dim);
+        return !(d2 > p.sph_thr[j]);
+    }
+    uint32_t b = j - p.n_spheres;
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if (k < dim) {
+            double v = s[k];
+            inside = inside && (v >= p.box_lo[(size_t)k * p.n_boxes + b]) && (v <= p.box_hi[(size_t)k * p.n_boxes + b]);
+        }
+    }
+    return inside;
+}
+
+// rrt.rs:90-116 evaluated data-parallel: the (step, obstacle) pairs are striped over the
+// `nthreads` callers; returns this thread's "found an invalid state" flag (caller ORs them).
+// is_valid is pure, so testing all steps equals the reference's first-invalid early exit.
+template <int D>
+__device__ __forceinline__ bool motion_invalid_partial(const DevParams& p, int dim, const double from[D],
+                                                       const double to[D], uint32_t tid, uint32_t nthreads) {
+    const uint32_t nobs = p.n_spheres + p.n_boxes;
+    if (nobs == 0) return false;
+    double dist = sqrt(dist2<D>(from, to, dim));
+    uint32_t nsteps = num_steps_u32(dist, p.res);
+    bool bad = false;
+    if (nsteps <= 1) {
+        for (uint32_t j = tid; j < nobs; j += nthreads) bad = bad || obstacle_hit<D>(p, dim, to, j);
+        return bad;
+    }
+    const uint64_t total = (uint64_t)nsteps * nobs;
+    const double dn = (double)nsteps;
+    for (uint64_t w = tid; w < total; w += nthreads) {
+        uint32_t step = (uint32_t)(w / nobs) + 1;
+        uint32_t j = (uint32_t)(w % nobs);
+        double t = (double)step / dn;
+        double s[D];
+        lerp<D>(from, to, t, s, dim);
+        bad = bad || obstacle_hit<D>(p, dim, s, j);
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------- nearest-neighbour reduction
+// The reference takes argmin over (sqrt(d2_i), i) with strict '<' (lowest index among ties).
+// The scan compares d2 (no sqrt per node) and also tracks the second-smallest d2: if it lies
+// within 3 ulps of the minimum, two different d2 may share one sqrt and the caller re-scans
+// exactly (post-sqrt compare).  At most 3 consecutive doubles share a correctly rounded sqrt.
+struct Best {
+    double b1;    // smallest d2
+    double b2;    // second smallest d2 (with multiplicity)
+    uint32_t i1;  // lowest index attaining b1
+};
+
+__device__ __forceinline__ Best best_init() { return Best{__builtin_inf(), __builtin_inf(), 0xFFFFFFFFu}; }
+
+__device__ __forceinline__ void best_push(Best& b, double d, uint32_t i) {
+    // indices arrive in increasing order within a lane, so strict '<' keeps the lowest index
+    bool lt = d < b.b1;
+    b.b2 = fmin(b.b2, fmax(b.b1, d));
+    b.b1 = lt ? d : b.b1;
+    b.i1 = lt ? i : b.i1;
+}
+
+__device__ __forceinline__ Best best_combine(const Best& a, const Best& b) {
+    bool bw = (b.b1 < a.b1) || (b.b1 == a.b1 && b.i1 < a.i1);
+    Best r;
+    r.b1 = bw ? b.b1 : a.b1;
+    r.i1 = bw ? b.i1 : a.i1;
+    r.b2 = fmin(fmin(a.b2, b.b2), bw ? a.b1 : b.b1);
+    return r;
+}
+
+__device__ __forceinline__ Best best_wave_reduce(Best v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Best o;
+        o.b1 = __shfl_xor(v.b1, off, 64);
+        o.b2 = __shfl_xor(v.b2, off, 64);
+        o.i1 = __shfl_xor(v.i1, off, 64);
+        v = best_combine(v, o);
+    }
+    return v;
+}
+
+// near-tie test: could another node's sqrt(d2) equal sqrt(b1)?
+__device__ __forceinline__ bool best_ambiguous(const Best& b) {
+    uint64_t bound = (uint64_t)__double_as_longlong(b.b1) + 3;  // b1 >= +0: bit pattern is monotone
+    return b.b2 <= __longlong_as_double((long long)bound);
+}
+
+// exact (post-sqrt) pair for the rare re-scan: lexicographic (dist, index)
+struct Exact {
+    double dist;
+    uint32_t idx;
+};
+__device__ __forceinline__ Exact exact_combine(const Exact& a, const Exact& b) {
+    bool bw = (b.dist < a.dist) || (b.dist == a.dist && b.idx < a.idx);
+    return bw ? b : a;
+}
+__device__ __forceinline__ Exact exact_wave_reduce(Exact v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        Exact o;
+        o.dist = __shfl_xor(v.dist, off, 64);
+        o.idx = __shfl_xor(v.idx, off, 64);
+        v = exact_combine(v, o);
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint64_t fnv_mix(uint64_t h, uint64_t v) { return (h ^ v) * kFnvPrime; }
+
+}  // namespace oxhip

@@ -1,0 +1,412 @@
+"""GPU parity tests: the HIP path (through the C ABI, ctypes) against the CPU oracle and the
+golden fixtures.  Bit-exact for every integer, index and f64 bit pattern.
+
+PARITY UNPINNED against oxmpl itself: the oracle is our C restatement (oracle/rrt_oracle.h);
+the reference holds no vectors for this path and cannot be built here.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from helpers import unhex, hexf, bits, params_spheres, params_boxes, is_path_valid
+
+pytestmark = pytest.mark.gpu
+
+from oxmpl_amd import capi, scenarios  # noqa: E402
+from oracle import oracle_py as orc  # noqa: E402
+
+KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT]
+KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident"}
+
+
+def _batch_or_skip(*args, **kw):
+    try:
+        return capi.RRTBatch(*args, **kw)
+    except capi.OxhipError as e:
+        if e.status == capi.ERR_BAD_ARG and "resident" in str(e):
+            pytest.skip("resident kernel has no instantiation for this shape")
+        raise
+
+
+def _oracle_for(sc, seed, pid, max_nodes, stop):
+    p = orc.OracleRRT(sc["dim"], sc["bounds"], sc["max_distance"], sc["goal_bias"], sc["lvs_fraction"],
+                      max_nodes, stop, seed, pid)
+    if sc["spheres"] is not None:
+        p.set_spheres(*sc["spheres"])
+    if sc["boxes"] is not None:
+        p.set_boxes(*sc["boxes"])
+    p.setup(sc["start"], sc["goal_centre"], sc["goal_radius"])
+    return p
+
+
+def _gpu_for(sc, n_problems, max_nodes, stop, seed, first_pid=0, kernel=0):
+    try:
+        return scenarios.make_batch(sc, n_problems, max_nodes, stop, seed, first_pid, 0, kernel)
+    except capi.OxhipError as e:
+        if e.status == capi.ERR_BAD_ARG and "resident" in str(e):
+            pytest.skip("resident kernel has no instantiation for this shape")
+        raise
+
+
+def _assert_same_problem(gpu, p, o, c=None):
+    c = c or gpu.counts()
+    assert int(c["nodes"][p]) == o.num_nodes
+    assert int(c["iterations"][p]) == o.iterations
+    assert int(c["accepted"][p]) == o.accepted
+    assert int(c["checksum"][p]) == o.checksum
+    assert int(c["goal_node"][p]) == o.goal_node
+    gs, gp = gpu.tree(p)
+    os_, op = o.tree()
+    assert np.array_equal(gp, op)
+    assert np.array_equal(bits(gs), bits(os_))
+    assert np.array_equal(bits(gpu.path(p)), bits(o.path()))
+
+
+# --------------------------------------------------------------------------- arithmetic
+def test_device_f64_arithmetic_is_ieee():
+    rng = np.random.default_rng(1)
+    # sqrt: wide exponent range, subnormals, perfect squares +-1 ulp, the 3-doubles-share-a-root case
+    mant = rng.random(200000) + 1.0
+    expo = rng.integers(-1000, 1000, size=mant.size)
+    x = np.ldexp(mant, expo)
+    sq = rng.random(50000) * 100.0
+    sq = sq * sq
+    x = np.concatenate([x, sq, np.nextafter(sq, np.inf), np.nextafter(sq, 0.0),
+                        [0.0, 5e-324, 2.2250738585072014e-308, 1.0, 1.0 + 2.0 ** -52, 1.0 + 2.0 ** -51, 4.0, np.inf,
+                         300.0, 800.0, 200.0, 1.7976931348623157e308]])
+    got = capi.f64_op_batch(0, x)
+    assert np.array_equal(bits(got), bits(np.sqrt(x)))
+    # division
+    a = np.ldexp(rng.random(200000) + 1.0, rng.integers(-300, 300, size=200000)) * rng.choice([-1.0, 1.0], 200000)
+    b = np.ldexp(rng.random(200000) + 1.0, rng.integers(-300, 300, size=200000))
+    got = capi.f64_op_batch(1, a, b)
+    assert np.array_equal(bits(got), bits(a / b))
+    a2 = np.array([0.5, 0.5, 1.0, 6.0, 0.0, 1.0, 0.0])
+    b2 = np.array([0.08660254037844389, 0.14142135623730953, 3.0, 6.0, 1.0, 0.0, 0.0])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = a2 / b2
+    assert np.array_equal(bits(capi.f64_op_batch(1, a2, b2)), bits(want))
+    # ceil
+    c = np.concatenate([rng.random(10000) * 20.0 - 10.0, [5.773502691896258, 6.0, -0.0, 0.0, 1e300, 0.9999999999999999]])
+    assert np.array_equal(bits(capi.f64_op_batch(2, c)), bits(np.ceil(c)))
+    # interpolate must NOT be contracted into an FMA: from + (to - from) * t, three roundings
+    f = rng.random(200000) * 20.0 - 10.0
+    t = rng.random(200000) * 20.0 - 10.0
+    tt = rng.random(200000)
+    want = f + (t - f) * tt
+    got = capi.f64_op_batch(3, f, t, tt)
+    assert np.array_equal(bits(got), bits(want))
+    # (a-b)^2
+    got = capi.f64_op_batch(4, f, t)
+    assert np.array_equal(bits(got), bits((f - t) * (f - t)))
+
+
+def test_device_rng_stream_matches_oracle(golden):
+    g = golden["rng"]
+    got = capi.rng_u64_batch(g["seed"], g["stream"], 40)
+    assert ["%016x" % int(v) for v in got] == g["u64"]
+    for seed, stream, n in [(0, 0, 8), (42, 1023, 1000), (2 ** 64 - 1, 2 ** 63 + 5, 777)]:
+        r = orc.Rng(seed, stream)
+        want = np.array([r.next_u64() for _ in range(n)], dtype=np.uint64)
+        assert np.array_equal(capi.rng_u64_batch(seed, stream, n), want)
+
+
+def test_distance_interpolate_batch(golden):
+    for dim in (1, 2, 3, 6):
+        ks = [k for k in golden["space"]["kat"] if len(k["a"]) == dim]
+        a = np.array([[unhex(v) for v in k["a"]] for k in ks])
+        b = np.array([[unhex(v) for v in k["b"]] for k in ks])
+        t = np.array([unhex(k["t"]) for k in ks])
+        assert [hexf(v) for v in capi.distance_batch(a, b)] == [k["distance"] for k in ks]
+        got = capi.interpolate_batch(a, b, t)
+        assert [[hexf(v) for v in row] for row in got] == [k["interpolate"] for k in ks]
+    rng = np.random.default_rng(5)
+    for dim in range(1, 9):
+        a = rng.random((4096, dim)) * 20 - 10
+        b = rng.random((4096, dim)) * 20 - 10
+        t = rng.random(4096)
+        want = np.array([orc.distance(x, y) for x, y in zip(a, b)])
+        assert np.array_equal(bits(capi.distance_batch(a, b)), bits(want))
+        want = np.array([orc.interpolate(x, y, tt) for x, y, tt in zip(a, b, t)])
+        assert np.array_equal(bits(capi.interpolate_batch(a, b, t)), bits(want))
+
+
+# ------------------------------------------------------------------------ nearest neighbour
+def test_nn_argmin_random_and_ragged():
+    rng = np.random.default_rng(7)
+    for dim in (1, 2, 3, 6, 8):
+        sizes = [1, 2, 63, 64, 65, 255, 256, 257, 1000, 4097, 10000]
+        trees = [rng.random((n, dim)) * 10.0 for n in sizes]
+        qs = rng.random((len(sizes), dim)) * 10.0
+        idx, md = capi.nn_argmin_batch(trees, qs)
+        for t, q, i, d in zip(trees, qs, idx, md):
+            wi, wd = orc.nearest(t, q)
+            assert (int(i), hexf(d)) == (wi, hexf(wd))
+
+
+def test_nn_argmin_ties_resolve_to_lowest_index():
+    y = 2.0 ** -26  # d2 = 1 + 2^-52 and d2 = 1 share sqrt == 1.0: the reference keeps the LOWER index
+    cases = [
+        (np.array([[1.0, 0.0], [-1.0, 0.0], [0.0, 1.0], [0.0, -1.0]]), [0.0, 0.0]),
+        (np.array([[1.0, y], [1.0, 0.0]]), [0.0, 0.0]),
+        (np.array([[1.0, 0.0], [1.0, y]]), [0.0, 0.0]),
+        (np.array([[3.0, 3.0]] * 700), [1.0, 1.0]),  # all duplicates -> index 0
+    ]
+    # near-ties hidden at every position of a large tree (inside one lane, across lanes, across waves)
+    rng = np.random.default_rng(11)
+    base = rng.random((3000, 2)) * 10.0 + 5.0
+    for pos_a, pos_b in [(0, 1), (5, 2999), (64, 128), (255, 256), (1234, 1234 + 256), (2999, 17)]:
+        t = base.copy()
+        t[pos_a] = [1.0, y]
+        t[pos_b] = [1.0, 0.0]
+        cases.append((t, [0.0, 0.0]))
+    trees = [c[0] for c in cases]
+    qs = np.array([c[1] for c in cases])
+    idx, md = capi.nn_argmin_batch(trees, qs)
+    for t, q, i, d in zip(trees, qs, idx, md):
+        wi, wd = orc.nearest(t, q)
+        assert (int(i), hexf(d)) == (wi, hexf(wd))
+    assert int(idx[1]) == 0 and int(idx[2]) == 0 and int(idx[3]) == 0
+
+
+# ------------------------------------------------------------------ validity / motion check
+@pytest.mark.parametrize("scn", ["config1", "wall", "config2"])
+def test_is_valid_and_check_motion_match_oracle(scn):
+    sc = getattr(scenarios, scn)()
+    gpu = _gpu_for(sc, 1, 100, True, 0)
+    o = _oracle_for(sc, 0, 0, 100, True)
+    rng = np.random.default_rng(3)
+    lo = np.array([b[0] for b in sc["bounds"]])
+    hi = np.array([b[1] for b in sc["bounds"]])
+    pts = rng.random((4000, sc["dim"])) * (hi - lo) + lo
+    if sc["spheres"] is not None:  # points exactly on / next to sphere surfaces
+        c, r = sc["spheres"]
+        on = c.copy()
+        on[:, 0] += r
+        pts = np.concatenate([pts, on, np.nextafter(on, np.inf), np.nextafter(on, -np.inf)])
+    if sc["boxes"] is not None:    # box faces are inclusive
+        blo, bhi = sc["boxes"]
+        pts = np.concatenate([pts, blo, bhi, np.nextafter(blo, -np.inf), np.nextafter(bhi, np.inf)])
+    want = np.array([o.is_valid(p) for p in pts])
+    assert np.array_equal(gpu.is_valid(pts), want)
+    assert 0 < want.sum() < len(want)
+    a = rng.random((3000, sc["dim"])) * (hi - lo) + lo
+    step = rng.random((3000, 1)) * 1.2
+    d = rng.standard_normal((3000, sc["dim"]))
+    b = a + d / np.linalg.norm(d, axis=1, keepdims=True) * step
+    b[:100] = a[:100]  # from == to -> num_steps == 0 -> is_valid(to)
+    want = np.array([o.check_motion(x, y) for x, y in zip(a, b)])
+    assert np.array_equal(gpu.check_motion(a, b), want)
+    assert 0 < want.sum() < len(want)
+    gpu.close()
+
+
+# --------------------------------------------------------------------------- planner parity
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+@pytest.mark.parametrize("key", ["config1", "wall"])
+def test_rrt_matches_golden_fixtures(golden, key, kernel):
+    """README quick-start (config 1) and the reference's own wall test scene: identical node
+    count, parents, state bits, path and checksum as the committed fixtures."""
+    params = golden[key]["params"]
+    sc = dict(dim=params["dim"], bounds=params["bounds"], max_distance=params["max_distance"],
+              goal_bias=params["goal_bias"], lvs_fraction=params["fraction"], start=params["start"],
+              goal_centre=params["goal_c"], goal_radius=params["goal_r"],
+              spheres=params_spheres(params) if params["spheres"] else None,
+              boxes=params_boxes(params) if params["boxes"] else None)
+    for run in golden[key]["runs"]:
+        gpu = _gpu_for(sc, 1, params["max_nodes"], True, run["seed"], run["pid"], kernel)
+        st = gpu.solve(params["max_iterations"])
+        assert st[0] == capi.OK
+        c = gpu.counts()
+        assert int(c["nodes"][0]) == run["n"]
+        assert int(c["iterations"][0]) == run["iterations"]
+        assert int(c["accepted"][0]) == run["accepted"]
+        assert "%016x" % int(c["checksum"][0]) == run["checksum"]
+        assert int(c["goal_node"][0]) == run["goal_node"]
+        assert int(c["stop_reason"][0]) == capi.STOP_GOAL
+        states, parents = gpu.tree(0)
+        m = len(run["first_parents"])
+        assert [[hexf(v) for v in row] for row in states[:m]] == run["first_states"]
+        assert list(parents[:m]) == run["first_parents"]
+        path = gpu.path(0)
+        assert [[hexf(v) for v in row] for row in path] == run["path"]
+        # the reference's own assertions (oxmpl/tests/rrt_rvss_tests.rs:168-185)
+        o = _oracle_for(sc, 0, 0, 10, True)
+        assert len(path) > 0
+        assert orc.distance(path[0], sc["start"]) < 1e-9
+        assert orc.distance(path[-1], sc["goal_centre"]) <= sc["goal_radius"]
+        assert is_path_valid(path, sc["bounds"], sc["lvs_fraction"], o.is_valid, orc.maximum_extent,
+                             orc.num_steps, orc.interpolate, orc.distance)
+        gpu.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+def test_rrt_config2_golden_and_oracle_batch(golden, kernel):
+    """config 2 (R^3, 64 spheres): a 48-problem batch grown for 1500 iterations each equals the
+    oracle problem by problem; problems 0, 1 also equal the committed numpy fixtures."""
+    sc = scenarios.config2()
+    c, r = params_spheres(golden["config2"]["params"])
+    assert np.array_equal(bits(c), bits(sc["spheres"][0])) and np.array_equal(bits(r), bits(sc["spheres"][1]))
+    P = 48
+    gpu = _gpu_for(sc, P, 10000, False, 42, 0, kernel)
+    st = gpu.solve(1500)
+    cnt = gpu.counts()
+    planners = [_oracle_for(sc, 42, p, 10000, False) for p in range(P)]
+    orc.solve_many(planners, 1500, threads=8)
+    for p in range(P):
+        _assert_same_problem(gpu, p, planners[p], cnt)
+        assert st[p] == (capi.OK if planners[p].goal_node >= 0 else capi.ERR_NO_SOLUTION_FOUND)
+    for run in golden["config2"]["runs"]:
+        if run["pid"] < P:
+            p = run["pid"]
+            assert "%016x" % int(cnt["checksum"][p]) == run["checksum"]
+            states, parents = gpu.tree(p)
+            m = len(run["first_parents"])
+            assert [[hexf(v) for v in row] for row in states[:m]] == run["first_states"]
+            assert [[hexf(v) for v in row] for row in gpu.path(p)] == run["path"]
+    gpu.close()
+    # sharding: problems 1000..1023 on their own batch equal the oracle's problem ids 1000..1023
+    gpu = _gpu_for(sc, 24, 10000, False, 42, 1000, kernel)
+    gpu.solve(600)
+    planners = [_oracle_for(sc, 42, 1000 + p, 10000, False) for p in range(24)]
+    orc.solve_many(planners, 600, threads=8)
+    for p in range(24):
+        _assert_same_problem(gpu, p, planners[p])
+    gpu.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
+    """dims 1..6, spheres+boxes mixed, goal_bias 0 / 1 / 0.5, more obstacles than one wave."""
+    rng = np.random.default_rng(21)
+    for dim, gb, ns, nb in [(1, 0.05, 0, 0), (2, 0.5, 3, 2), (3, 1.0, 70, 0), (3, 0.0, 130, 5), (4, 0.1, 10, 1),
+                            (6, 0.05, 20, 0)]:
+        bounds = [(-3.0, 7.0)] * dim
+        sc = dict(dim=dim, bounds=bounds, max_distance=0.7, goal_bias=gb, lvs_fraction=0.02,
+                  start=[-2.5] * dim, goal_centre=[6.5] * dim, goal_radius=0.4,
+                  spheres=(rng.random((ns, dim)) * 6.0 - 1.0, rng.random(ns) * 0.5 + 0.1) if ns else None,
+                  boxes=None)
+        if nb:
+            lo = rng.random((nb, dim)) * 6.0 - 1.0
+            sc["boxes"] = (lo, lo + rng.random((nb, dim)) * 0.8 + 0.1)
+        P = 6
+        gpu = _gpu_for(sc, P, 400, False, 7, 100, kernel)
+        gpu.solve(500)
+        planners = [_oracle_for(sc, 7, 100 + p, 400, False) for p in range(P)]
+        orc.solve_many(planners, 500, threads=6)
+        for p in range(P):
+            _assert_same_problem(gpu, p, planners[p])
+        gpu.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+def test_rrt_termination_resume_and_freeze(kernel):
+    sc = scenarios.config2()
+    # node cap: stops at max_nodes without drawing further
+    gpu = _gpu_for(sc, 4, 300, False, 5, 0, kernel)
+    gpu.solve(10 ** 6)
+    c = gpu.counts()
+    planners = [_oracle_for(sc, 5, p, 300, False) for p in range(4)]
+    for o in planners:
+        o.solve(10 ** 6)
+    for p in range(4):
+        assert int(c["nodes"][p]) == 300 and int(c["stop_reason"][p]) == capi.STOP_NODES
+        _assert_same_problem(gpu, p, planners[p], c)
+    it0 = c["iterations"].copy()
+    gpu.solve(100)
+    assert np.array_equal(gpu.counts()["iterations"], it0)
+    gpu.close()
+    # resume: 300 + 500 iterations == 800 iterations; then 256 frozen iterations
+    gpu = _gpu_for(sc, 4, 10000, False, 9, 0, kernel)
+    gpu.solve(300)
+    gpu.solve(500)
+    planners = [_oracle_for(sc, 9, p, 10000, False) for p in range(4)]
+    for o in planners:
+        o.solve(800)
+    for p in range(4):
+        _assert_same_problem(gpu, p, planners[p])
+    n0 = gpu.counts()["nodes"].copy()
+    gpu.solve(256, freeze=True)
+    for o in planners:
+        o.solve(256, freeze=True)
+    c = gpu.counts()
+    assert np.array_equal(c["nodes"], n0)
+    for p in range(4):
+        _assert_same_problem(gpu, p, planners[p], c)
+    gpu.close()
+    # stop_at_goal: solved problems are left alone by a second solve (idempotent)
+    gpu = _gpu_for(sc, 8, 10000, True, 42, 0, kernel)
+    st = gpu.solve(100000)
+    assert (st == capi.OK).all()
+    c1 = gpu.counts()
+    assert (c1["stop_reason"] == capi.STOP_GOAL).all()
+    gpu.solve(1000)
+    c2 = gpu.counts()
+    assert np.array_equal(c1["iterations"], c2["iterations"]) and np.array_equal(c1["nodes"], c2["nodes"])
+    planners = [_oracle_for(sc, 42, p, 10000, True) for p in range(8)]
+    for p, o in enumerate(planners):
+        assert o.solve(100000) == orc.SOLVED
+        _assert_same_problem(gpu, p, o, c2)
+    gpu.close()
+    # timeout: every motion is invalid (one huge sphere), so the tree never grows and the
+    # iteration budget cannot be reached -> wall-clock Timeout (rrt.rs:172-174)
+    blocked = dict(sc)
+    blocked["spheres"] = (np.array([[5.0, 5.0, 5.0]]), np.array([100.0]))
+    gpu = _gpu_for(blocked, 2, 1000, True, 1, 0, kernel)
+    st = gpu.solve(10 ** 12, timeout_s=0.05)
+    assert (st == capi.ERR_TIMEOUT).all()
+    c = gpu.counts()
+    assert (c["stop_reason"] == capi.STOP_TIMEOUT).all() and (c["nodes"] == 1).all() and (c["accepted"] == 0).all()
+    gpu.close()
+
+
+def test_solve_before_setup_is_planner_uninitialised():
+    b = capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.1, 0.0, 1, 10)
+    with pytest.raises(capi.OxhipError) as ei:
+        b.solve(10)
+    assert ei.value.status == capi.ERR_PLANNER_UNINITIALISED  # rrt.rs:160-163
+    b.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+def test_full_size_config2_properties(kernel):
+    """BASELINE.json configs[1] at full size (1024 problems x 10,000 nodes): size-independent
+    properties on every problem + exact oracle parity on a sample of problems."""
+    sc = scenarios.config2()
+    P, N = 1024, 10000
+    gpu = _gpu_for(sc, P, N, False, 42, 0, kernel)
+    gpu.solve(10 ** 7)
+    c = gpu.counts()
+    assert (c["nodes"] == N).all() and (c["stop_reason"] == capi.STOP_NODES).all()
+    assert (c["accepted"] == N - 1).all()
+    assert (c["iterations"] >= N - 1).all()
+    assert (c["goal_node"] > 0).all()
+    assert len(set(int(v) for v in c["checksum"])) == P  # independent streams
+    o = _oracle_for(sc, 0, 0, 10, True)
+    for p in range(0, P, 37):
+        states, parents = gpu.tree(p)
+        assert parents[0] == -1 and (parents[1:] >= 0).all() and (parents[1:] < np.arange(1, N)).all()
+        edge = np.sqrt(((states[1:] - states[parents[1:]]) ** 2).sum(axis=1))
+        assert edge.max() <= 0.5 * (1 + 1e-12)  # steer never exceeds max_distance
+        assert (states >= 0.0).all() and (states <= 10.0).all()
+        assert gpu.is_valid(states[1:]).all()   # every inserted state passed the motion check
+        path = gpu.path(p)
+        assert np.array_equal(bits(path[0]), bits(np.array(sc["start"])))
+        assert orc.distance(path[-1], sc["goal_centre"]) <= sc["goal_radius"]
+        assert is_path_valid(path, sc["bounds"], sc["lvs_fraction"], o.is_valid, orc.maximum_extent,
+                             orc.num_steps, orc.interpolate, orc.distance)
+    sample = [0, 1, 255, 256, 511, 777, 1022, 1023]
+    planners = [_oracle_for(sc, 42, p, N, False) for p in sample]
+    orc.solve_many(planners, 10 ** 7, threads=8)
+    for p, pl in zip(sample, planners):
+        _assert_same_problem(gpu, p, pl, c)
+    # steady mode at n = 10,000: 64 frozen iterations, checksum parity on the sample
+    gpu.solve(64, freeze=True)
+    orc.solve_many(planners, 64, freeze=True, threads=8)
+    c = gpu.counts()
+    for p, pl in zip(sample, planners):
+        assert int(c["checksum"][p]) == pl.checksum and int(c["iterations"][p]) == pl.iterations
+        assert int(c["accepted"][p]) == pl.accepted and int(c["nodes"][p]) == N
+    gpu.close()
