@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- RRT iterations/sec (batched problems), R^3, 10k-node trees, 64-sphere field.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], one GPU; configs[2] = the same, 1024 problems per rank):
+1024 independent planning problems per GPU, trees pre-grown (untimed) to 10,000 nodes; one
+"step" = every problem runs ITERS further RRT iterations with inserts suppressed (freeze), so
+every nearest-neighbour scan covers exactly 10,000 nodes: sample -> NN -> steer -> motion
+check (6 states x 64 spheres) per iteration, nothing skipped but the push.  Inputs are resident
+in HBM before the timed region; problems are sharded across ranks with no data-path collective
+(weak scaling); torch.distributed (RCCL) is used for the barriers and the throughput gather.
+
+One JSON line on rank 0.  `roofline` prices the grow kernel against the HBM roofline with
+ALGORITHMIC bytes (24 B x tree size per iteration); `cpu_baseline` times the CPU
+oracle (our C restatement of oxmpl's loop, kind "port") on a bounded sample of the same
+workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_NODES = 10000
+BYTES_PER_ITER = N_NODES * 3 * 8          # B(n) = n * d * 8
+HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(sc, seed, threads, iters):
+    """Oracle (kind 'port') on `threads` host cores: `threads` problems grown to 10k nodes
+    (untimed), then `iters` frozen iterations each (timed) -- same per-iteration work as the GPU step."""
+    from oracle import oracle_py as orc
+    planners = []
+    for p in range(threads):
+        o = orc.OracleRRT(sc["dim"], sc["bounds"], sc["max_distance"], sc["goal_bias"], sc["lvs_fraction"],
+                          N_NODES, False, seed, p)
+        o.set_spheres(*sc["spheres"])
+        o.setup(sc["start"], sc["goal_centre"], sc["goal_radius"])
+        planners.append(o)
+    orc.solve_many(planners, 10 ** 7, threads=threads)
+    assert all(p.num_nodes == N_NODES for p in planners)
+    t0 = time.perf_counter()
+    orc.solve_many(planners, iters, freeze=True, threads=threads)
+    dt = time.perf_counter() - t0
+    return planners, dict(value=threads * iters / dt, unit="iterations/s", cores=threads, kind="port",
+                          sample="%d problems x %d frozen iterations at n=10000 on %d threads "
+                                 "(oracle/rrt_oracle.c, C restatement of rrt.rs:170-225)" % (threads, iters, threads))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--problems", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--iters", type=int, default=4096, help="RRT iterations per problem per step")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+
+    import torch  # plumbing only: device sync + torch.distributed (RCCL) barriers / gather
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    import numpy as np
+    from oxmpl_amd import capi, scenarios
+
+    sc = scenarios.config2()
+    P, seed = args.problems, 42
+    gpu = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=rank * P,
+                               device=local_rank, kernel=args.kernel)
+    # untimed: grow every tree to 10,000 nodes (also the "grow" figure reported below)
+    barrier()
+    t0 = time.perf_counter()
+    gpu.solve(10 ** 7)
+    torch.cuda.synchronize()
+    grow_s = time.perf_counter() - t0
+    grow_t = gpu.last_timing()
+    c = gpu.counts()
+    assert (c["nodes"] == N_NODES).all()
+    grow_iters = int(c["iterations"].sum())
+
+    for _ in range(args.warmup):
+        gpu.solve(args.iters, freeze=True)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        gpu.solve(args.iters, freeze=True)
+        t = gpu.last_timing()           # HIP events on the library's own stream
+        kernel_ms += t["kernel_ms"]
+        launches += t["launches"]
+    barrier()
+    dt = time.perf_counter() - t0
+    c2 = gpu.counts()
+    done = int((c2["iterations"] - c["iterations"]).sum())
+    assert done == P * args.iters * (args.steps + args.warmup)
+    iters_timed = P * args.iters * args.steps
+
+    stats = torch.tensor([dt, float(iters_timed), kernel_ms, float(launches), float(grow_iters), grow_s,
+                          grow_t["kernel_ms"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        allst = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(allst, stats)   # RCCL all-gather over xGMI: throughput report only
+        allst = torch.stack(allst).cpu().numpy()
+    else:
+        allst = stats.cpu().numpy()[None, :]
+
+    if rank == 0:
+        t_max = float(allst[:, 0].max())
+        total_iters = float(allst[:, 1].sum())
+        value = total_iters / t_max
+        avg_launch_ms = float(allst[0, 2] / allst[0, 3])
+        iters_per_launch = P * args.iters
+        achieved = iters_per_launch * BYTES_PER_ITER / (avg_launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "RRT iterations/sec (batched problems), R^3 10k-node tree, 64-sphere field",
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: R^3 RRT, 64 random spheres, %d problem instances per MI355X, "
+                                   "steady@10k (trees pre-grown to 10000 nodes, inserts suppressed)" % P,
+                       "problems_per_gpu": P, "iterations_per_problem_per_step": args.iters, "tree_nodes": N_NODES,
+                       "spheres": 64, "max_distance": 0.5, "goal_bias": 0.05, "parallelism": "problem-parallel x%d" % world,
+                       "kernel": {1: "stream", 2: "resident"}[gpu.last_timing()["kernel"]]},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_avg_ms": avg_launch_ms, "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER},
+            "grow": {"iterations": float(allst[:, 4].sum()), "wall_s": float(allst[:, 5].max()),
+                     "iterations_per_s": float(allst[:, 4].sum() / allst[:, 5].max()),
+                     "kernel_ms_rank0": float(allst[0, 6])},
+        }
+        if not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, 16)
+            planners, base = cpu_baseline(sc, seed, threads, 6000)
+            out["cpu_baseline"] = base
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    gpu.close()
+
+
+if __name__ == "__main__":
+    main()
