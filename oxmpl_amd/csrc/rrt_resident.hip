@@ -1,8 +1,328 @@
-// rrt_resident.hip -- register-resident RRT grow kernel (placeholder until the kernel lands).
+// rrt_resident.hip -- register-resident RRT grow kernel for gfx950.
+//
+// One 1024-thread workgroup (16 wave64 = the whole register file of one CU) per problem.
+// Thread t keeps tree nodes {t + 1024*s : s < S} in its VGPRs (S*DIM f64 = 60 VGPRs for
+// R^3, 10,240 nodes), so the O(n) nearest-neighbour scan of rrt.rs:187-196 reads no memory
+// at all: it is bounded by f64 VALU issue, not by HBM.  The SoA tree in HBM is only the
+// persistent copy (written once per insert, read once at launch).
+//
+// Per iteration: every wave scans its 640 nodes (d2 compare, no sqrt), reduces with DPP,
+// publishes (d2, index, candidate coordinates) to LDS; after one barrier every wave derives
+// the same nearest node, steers, and the 16 waves split the motion check's interpolated
+// states (one state per wave, one obstacle per lane); a second barrier ORs the verdicts.
+//
+// Replaces the loop body of RRT::solve, oxmpl/src/geometric/planners/rrt.rs:170-225.
 #include "oxhip_internal.hpp"
 #include "rrt_device.hpp"
 
 namespace oxhip {
-bool resident_supported(uint32_t, uint32_t) { return false; }
-void launch_rrt_resident(const DevParams&, hipStream_t) {}
+
+constexpr int kResThreads = 1024;
+constexpr int kResWaves = kResThreads / 64;
+
+// ---- wave64 min of an f64 with DPP (VALU only, no LDS crossbar); result is wave-uniform
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_min_step(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // bound_ctrl = false + old = own value: lanes without a source keep their own value
+    int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmin(v, __hiloint2double(ohi, olo));
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = dpp_min_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_min_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_min_step<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_min_step<0x140, 0xf>(v);  // row_mirror          -> every lane holds its row's min
+    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave min
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double bound3(double g) {
+    return __longlong_as_double((long long)((uint64_t)__double_as_longlong(g) + 3));
+}
+
+template <int DIM>
+struct WavePub {      // one wave's nearest-neighbour candidate
+    double b1;        // its smallest d2
+    uint32_t i1;      // lowest index attaining it
+    uint32_t amb;     // the wave saw another d2 within 3 ulps of b1
+    double c[DIM];    // the candidate's coordinates
+};
+template <int DIM>
+struct WaveExact {
+    double dist;
+    uint32_t idx;
+    uint32_t pad;
+    double c[DIM];
+};
+
+// static-index fetch of slot `slot` (wave-uniform) from the register tree
+template <int DIM, int S>
+__device__ __forceinline__ void fetch_slot(const double (&tr)[DIM][S], uint32_t slot, double c[DIM]) {
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) c[k] = 0.0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (slot == (uint32_t)s) {  // uniform branch; every index below is a compile-time constant
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) c[k] = tr[k][s];
+        }
+    }
+}
+
+template <int DIM, int S>
+__global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) {
+    constexpr int D = DIM;
+    const uint32_t prob = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = uni(tid >> 6), lane = tid & 63;
+
+    __shared__ uint32_t rng_buf[16][64];
+    __shared__ WavePub<DIM> pub[kResWaves];
+    __shared__ WaveExact<DIM> epub[kResWaves];
+    __shared__ uint32_t bad_flag[2];
+
+    ProblemState st = p.state[prob];
+    if (p.stop_at_goal && st.goal_node >= 0) return;
+
+    const size_t cap = p.cap;
+    double* tree = p.tree + (size_t)prob * DIM * cap;
+    int32_t* parent = p.parent + (size_t)prob * cap;
+    double goal_c[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
+    const double goal_thr = p.goal_thr[prob];
+    const uint32_t nobs = p.n_spheres + p.n_boxes;
+
+    uint32_t n = st.n_nodes;
+
+    // the tree, in registers: node (tid + 1024*s) in tr[.][s]; empty slots hold +inf (d2 = inf never wins)
+    double tr[DIM][S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        uint32_t i = tid + kResThreads * s;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) tr[k][s] = (i < n) ? tree[(size_t)k * cap + i] : __builtin_inf();
+    }
+
+    RngWindow rng;
+    rng.init(rng_buf, p.seed, p.first_problem_id + prob, st.draws);
+    if (tid < 2) bad_flag[tid] = 0;
+    __syncthreads();
+
+    uint32_t par = 0;
+    int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
+    for (uint64_t it = 0; it < p.budget; ++it, par ^= 1) {
+        if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
+
+        // 2. sample (rrt.rs:177-184): every wave derives the same q from the LDS word window
+        double q[D];
+        sample_state<D>(rng, p, DIM, goal_c, q);
+
+        // 3. nearest neighbour (rrt.rs:187-196) over the register tree
+        const uint32_t nslots = uni((n + kResThreads - 1) / kResThreads);
+        Best best = best_init();
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if ((uint32_t)s < nslots) {
+                double c[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) c[k] = tr[k][s];
+                best_push(best, dist2<D>(c, q, DIM), tid + kResThreads * s);
+            }
+        }
+        {
+            const double wmin = wave_min_f64(best.b1);
+            const uint64_t eqm = __ballot(best.b1 == wmin);
+            const int wl = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
+            const uint32_t widx = __builtin_amdgcn_readlane(best.i1, wl);
+            const double bnd = bound3(wmin);
+            const bool amb_l = ((int)lane != wl && best.b1 <= bnd) || (best.b2 <= bnd);
+            const uint32_t wamb = __ballot(amb_l) != 0 ? 1u : 0u;
+            double c[D], cw[D];
+            fetch_slot<DIM, S>(tr, widx >> 10, c);
+            // readlanes stay outside the lane-0 branch so lane wl's registers are live there
+#pragma unroll
+            for (int k = 0; k < D; ++k) cw[k] = readlane_f64(c[k], wl);
+            if (lane == 0) {
+                WavePub<DIM> w;
+                w.b1 = wmin; w.i1 = widx; w.amb = wamb;
+#pragma unroll
+                for (int k = 0; k < D; ++k) w.c[k] = cw[k];
+                pub[wave] = w;
+            }
+        }
+        __syncthreads();
+
+        uint32_t nearest;
+        double min_dist;
+        double q_near[D];
+        {
+            const bool in = lane < kResWaves;
+            const double pb = in ? pub[in ? lane : 0].b1 : __builtin_inf();
+            const uint32_t pamb = in ? pub[in ? lane : 0].amb : 0u;
+            const double g = wave_min_f64(pb);
+            const uint64_t m2 = __ballot(in && pb == g);
+            const int ww = m2 ? (__ffsll((unsigned long long)m2) - 1) : 0;
+            const double bnd = bound3(g);
+            const bool amb = (__popcll(m2) > 1) || (__ballot(in && (pamb != 0 || ((int)lane != ww && pb <= bnd))) != 0);
+            if (!amb) {
+                nearest = pub[ww].i1;
+                min_dist = sqrt(g);
+#pragma unroll
+                for (int k = 0; k < D; ++k) q_near[k] = pub[ww].c[k];
+            } else {
+                // rare: post-sqrt compare with lowest-index ties, exactly as the reference
+                Exact e{__builtin_inf(), 0xFFFFFFFFu};
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if ((uint32_t)s < nslots) {
+                        double c[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) c[k] = tr[k][s];
+                        double d = sqrt(dist2<D>(c, q, DIM));
+                        if (d < e.dist) { e.dist = d; e.idx = tid + kResThreads * s; }
+                    }
+                }
+                e = exact_wave_reduce(e);
+                const uint32_t eidx = uni(e.idx);
+                double c[D], cw[D];
+                fetch_slot<DIM, S>(tr, eidx >> 10, c);
+                const int owner = (int)(eidx & 63u);
+#pragma unroll
+                for (int k = 0; k < D; ++k) cw[k] = readlane_f64(c[k], owner);
+                if (lane == 0) {
+                    WaveExact<DIM> w;
+                    w.dist = unid(e.dist); w.idx = eidx; w.pad = 0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) w.c[k] = cw[k];
+                    epub[wave] = w;
+                }
+                __syncthreads();
+                int bw = 0;
+                Exact be{epub[0].dist, epub[0].idx};
+                for (int w = 1; w < kResWaves; ++w) {
+                    Exact o{epub[w].dist, epub[w].idx};
+                    if ((o.dist < be.dist) || (o.dist == be.dist && o.idx < be.idx)) { be = o; bw = w; }
+                }
+                nearest = be.idx;
+                min_dist = be.dist;
+#pragma unroll
+                for (int k = 0; k < D; ++k) q_near[k] = epub[bw].c[k];
+            }
+        }
+        nearest = uni(nearest);
+
+        // 4. steer (rrt.rs:199-208)
+        double q_new[D];
+        if (min_dist > p.max_distance) {
+            double t = p.max_distance / min_dist;
+            lerp<D>(q_near, q, t, q_new, DIM);
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) q_new[k] = q[k];
+        }
+
+        // 5. check_motion (rrt.rs:90-116): interpolated states striped over the 16 waves,
+        //    obstacles over the lanes
+        bool bad = false;
+        if (nobs > 0) {
+            const double dist = sqrt(dist2<D>(q_near, q_new, DIM));
+            const uint32_t nsteps = num_steps_u32(dist, p.res);
+            if (nsteps <= 1) {
+                if (wave == 0)
+                    for (uint32_t j = lane; j < nobs; j += 64) bad = bad || obstacle_hit<D>(p, DIM, q_new, j);
+            } else {
+                const double dn = (double)nsteps;
+                for (uint32_t s = wave + 1; s <= nsteps; s += kResWaves) {
+                    const double t = (double)s / dn;
+                    double x[D];
+                    lerp<D>(q_near, q_new, t, x, DIM);
+                    for (uint32_t j = lane; j < nobs; j += 64) bad = bad || obstacle_hit<D>(p, DIM, x, j);
+                }
+            }
+        }
+        if (__ballot(bad) != 0 && lane == 0) bad_flag[par] = 1;
+        if (tid == 0) bad_flag[par ^ 1] = 0;  // re-arm the other parity for the next iteration
+        __syncthreads();
+        const bool ok = bad_flag[par] == 0;
+
+        if (wave == 0) {  // bookkeeping is only ever read back from thread 0
+            uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
+#pragma unroll
+            for (int k = 0; k < D; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(q_new[k]));
+            st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
+            st.iterations++;
+            if (ok) st.accepted++;
+        }
+
+        bool hit = false;
+        if (ok && !p.freeze) {
+            // 6. insert (rrt.rs:213-217): the owner thread takes the node into its registers
+            const uint32_t slot = n >> 10;
+            const bool owner = tid == (n & (kResThreads - 1));
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (slot == (uint32_t)s) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) tr[k][s] = owner ? q_new[k] : tr[k][s];
+                }
+            }
+            if (owner) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) tree[(size_t)k * cap + n] = q_new[k];
+                parent[n] = (int32_t)nearest;
+            }
+            ++n;
+            // 7. goal test (rrt.rs:220-223)
+            if (dist2<D>(q_new, goal_c, DIM) <= goal_thr) {
+                if (st.goal_node < 0) st.goal_node = (int32_t)(n - 1);
+                hit = true;
+            }
+        }
+        if (hit && p.stop_at_goal) { stop = 0; break; }
+    }
+
+    if (tid == 0) {
+        st.n_nodes = n;
+        st.draws = rng.pos;
+        st.stop_reason = stop;
+        p.state[prob] = st;
+    }
+}
+
+// instantiations: (dim, slots) -> capacity 1024 * slots nodes
+static int pick_slots(uint32_t cap) {
+    const uint32_t need = (cap + kResThreads - 1) / kResThreads;
+    if (need <= 2) return 2;
+    if (need <= 4) return 4;
+    if (need <= 10) return 10;
+    return 0;
+}
+
+bool resident_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && pick_slots(cap) != 0; }
+
+void launch_rrt_resident(const DevParams& p, hipStream_t stream) {
+    dim3 grid(p.n_problems), block(kResThreads);
+    const int s = pick_slots(p.cap);
+#define OXHIP_LAUNCH(DIM_, S_) hipLaunchKernelGGL((rrt_resident_kernel<DIM_, S_>), grid, block, 0, stream, p)
+    if (p.dim == 3) {
+        if (s == 2) OXHIP_LAUNCH(3, 2); else if (s == 4) OXHIP_LAUNCH(3, 4); else OXHIP_LAUNCH(3, 10);
+    } else {
+        if (s == 2) OXHIP_LAUNCH(2, 2); else if (s == 4) OXHIP_LAUNCH(2, 4); else OXHIP_LAUNCH(2, 10);
+    }
+#undef OXHIP_LAUNCH
+}
+
 }  // namespace oxhip
