@@ -25,7 +25,8 @@ EXPORTS = [
     "oxhip_rrt_batch_create", "oxhip_rrt_batch_destroy", "oxhip_rrt_batch_set_spheres",
     "oxhip_rrt_batch_set_boxes", "oxhip_rrt_batch_setup", "oxhip_rrt_batch_solve",
     "oxhip_rrt_batch_get_counts", "oxhip_rrt_batch_get_tree", "oxhip_rrt_batch_get_path",
-    "oxhip_rrt_batch_last_timing", "oxhip_nn_argmin_batch", "oxhip_distance_batch",
+    "oxhip_rrt_batch_last_timing", "oxhip_rrt_batch_enable_stamps", "oxhip_rrt_batch_get_stamps",
+    "oxhip_nn_argmin_batch", "oxhip_distance_batch",
     "oxhip_interpolate_batch", "oxhip_rrt_batch_is_valid", "oxhip_rrt_batch_check_motion",
     "oxhip_f64_op_batch", "oxhip_rng_u64_batch",
 ]
@@ -92,6 +93,8 @@ def lib():
         L.oxhip_rrt_batch_get_tree.argtypes = [C.c_void_p, C.c_uint32, _dp, _i32p, C.c_uint32, _u32p]
         L.oxhip_rrt_batch_get_path.argtypes = [C.c_void_p, C.c_uint32, _dp, C.c_uint32, _u32p]
         L.oxhip_rrt_batch_last_timing.argtypes = [C.c_void_p, _dp, _u32p, _u32p]
+        L.oxhip_rrt_batch_enable_stamps.argtypes = [C.c_void_p, C.c_uint32]
+        L.oxhip_rrt_batch_get_stamps.argtypes = [C.c_void_p, _u64p]
         L.oxhip_nn_argmin_batch.argtypes = [C.c_int32, C.c_uint32, _dp, _u32p, C.c_uint32, _dp, _u32p, _dp]
         L.oxhip_distance_batch.argtypes = [C.c_int32, C.c_uint32, _dp, _dp, C.c_uint32, _dp]
         L.oxhip_interpolate_batch.argtypes = [C.c_int32, C.c_uint32, _dp, _dp, _dp, C.c_uint32, _dp]
@@ -221,6 +224,14 @@ class RRTBatch:
         ms, launches, kind = C.c_double(), C.c_uint32(), C.c_uint32()
         _check(lib().oxhip_rrt_batch_last_timing(self._h, C.byref(ms), C.byref(launches), C.byref(kind)))
         return dict(kernel_ms=ms.value, launches=launches.value, kernel=kind.value)
+
+    def enable_stamps(self, enable=True):
+        _check(lib().oxhip_rrt_batch_enable_stamps(self._h, int(bool(enable))))
+
+    def stamps(self):
+        out = np.zeros(32, dtype=np.uint64)
+        _check(lib().oxhip_rrt_batch_get_stamps(self._h, _p(out, _u64p)))
+        return out
 
     def is_valid(self, states):
         s = _f64(states).reshape(-1, self.dim)

@@ -118,6 +118,7 @@ struct oxhip_rrt_batch {
     DevBuf<double> tree, goal_c, goal_thr, sph_c, sph_thr, box_lo, box_hi;
     DevBuf<int32_t> parent;
     DevBuf<ProblemState> state;
+    DevBuf<uint64_t> dbg;
     std::vector<double> starts;  // host copy, [P][dim]
     bool is_setup = false;
     double last_kernel_ms = 0.0;
@@ -491,6 +492,31 @@ int32_t oxhip_rrt_batch_last_timing(oxhip_rrt_batch* b, double* kernel_ms, uint3
     if (kernel_ms) *kernel_ms = b->last_kernel_ms;
     if (launches) *launches = b->last_launches;
     if (kernel_kind) *kernel_kind = b->kernel_kind;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_enable_stamps(oxhip_rrt_batch* b, uint32_t enable) {
+    if (!b) return fail(OXHIP_ERR_BAD_ARG, "null batch");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    if (enable) {
+        HIP_TRY(b->dbg.alloc(32));
+        HIP_TRY(hipMemsetAsync(b->dbg.p, 0, 32 * sizeof(uint64_t), b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        b->dp.dbg = b->dbg.p;
+    } else {
+        b->dp.dbg = nullptr;
+    }
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out) {
+    if (!b || !out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (!b->dp.dbg) return fail(OXHIP_ERR_BAD_ARG, "stamps are not enabled");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    HIP_TRY(hipMemcpyAsync(out, b->dbg.p, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
     return OXHIP_OK;
 }
 

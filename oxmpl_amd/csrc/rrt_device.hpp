@@ -55,6 +55,7 @@ struct DevParams {
     ProblemState* state;    // [P]
     const double* goal_c;   // [P][dim]
     const double* goal_thr; // [P]  satisfied iff d2 <= thr (== sqrt(d2) <= radius, exactly)
+    uint64_t* dbg;          // optional [16] cycle stamps of workgroup 0 (diagnostic build of the resident kernel)
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -106,10 +107,13 @@ struct RngWindow {
         buf = lds; seed = seed_; stream = stream_; pos = pos_;
         base_blk = (pos_ >> 3) - 64;  // forces a refill on first use (modular arithmetic)
     }
+    // WG_SYNC = true: every thread of the workgroup calls next() in the same sequence (barriers
+    // around the refill).  WG_SYNC = false: the window is private to wave 0 (LDS is in-order per wave).
+    template <bool WG_SYNC = true>
     __device__ __forceinline__ uint64_t next() {
         uint64_t blk = uni64(pos >> 3);
         if (blk - base_blk >= 64) {  // workgroup-uniform
-            __syncthreads();         // everybody is done reading the old window
+            if (WG_SYNC) __syncthreads();  // everybody is done reading the old window
             base_blk = blk;
             if (threadIdx.x < 64) {
                 uint32_t o[16];
@@ -117,7 +121,7 @@ struct RngWindow {
 #pragma unroll
                 for (int w = 0; w < 16; ++w) buf[w][threadIdx.x] = o[w];
             }
-            __syncthreads();
+            if (WG_SYNC) __syncthreads();
         }
         uint32_t l = uni((uint32_t)(blk - base_blk));
         uint32_t w = uni((uint32_t)(pos & 7) * 2);
@@ -129,12 +133,12 @@ struct RngWindow {
 
 // rrt.rs:177-184 + real_vector_state_space.rs:233-249 with rand 0.9's transforms.
 // Returns true when the goal was sampled (q = goal centre, no further draw).
-template <int D>
+template <int D, bool WG_SYNC = true>
 __device__ __forceinline__ bool sample_state(RngWindow& rng, const DevParams& p, int dim, const double* goal_c,
                                              double q[D]) {
     bool goal;
     if (p.p_int == ~0ull) goal = true;            // Bernoulli ALWAYS_TRUE: no draw
-    else goal = rng.next() < p.p_int;             // one u64
+    else goal = rng.next<WG_SYNC>() < p.p_int;    // one u64
     if (goal) {
 #pragma unroll
         for (int k = 0; k < D; ++k) if (k < dim) q[k] = goal_c[k];
@@ -145,7 +149,7 @@ __device__ __forceinline__ bool sample_state(RngWindow& rng, const DevParams& p,
         if (k < dim) {
             double res;
             for (;;) {
-                uint64_t bits = (rng.next() >> 12) | 0x3FF0000000000000ull;
+                uint64_t bits = (rng.next<WG_SYNC>() >> 12) | 0x3FF0000000000000ull;
                 double v01 = __longlong_as_double((long long)bits) - 1.0;
                 res = v01 * p.scale[k];
                 res = res + p.lo[k];

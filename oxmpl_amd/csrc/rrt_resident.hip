@@ -81,7 +81,51 @@ __device__ __forceinline__ void fetch_slot(const double (&tr)[DIM][S], uint32_t 
     }
 }
 
-template <int DIM, int S>
+// next query, written by the resolver one iteration ahead
+template <int DIM>
+struct QRec {
+    double q[DIM];
+    uint64_t pos_after;  // stream position after this query's draws
+};
+
+// what the resolver hands to the motion-check waves and to the insert step
+template <int DIM>
+struct Work {
+    double q_near[DIM];
+    double q_new[DIM];
+    uint32_t nearest;
+    uint32_t nsteps;
+    uint32_t mode;   // 0 = resolved, 1 = exact re-scan requested
+    uint32_t pad;
+    double t[64];    // t[s-1] = s / nsteps for s <= 64 (one f64 division per lane, in parallel)
+};
+
+// steer (rrt.rs:199-208) + the scalar part of check_motion (rrt.rs:95-97,105); resolver wave only
+template <int DIM>
+__device__ __forceinline__ void resolve_tail(const DevParams& p, uint32_t lane, uint32_t nearest, double min_dist,
+                                             const double q_near[DIM], const double q[DIM], Work<DIM>& work) {
+    double q_new[DIM];
+    if (min_dist > p.max_distance) {
+        double t = p.max_distance / min_dist;
+        lerp<DIM>(q_near, q, t, q_new, DIM);
+    } else {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) q_new[k] = q[k];
+    }
+    const double dist = sqrt(dist2<DIM>(q_near, q_new, DIM));
+    const uint32_t nsteps = num_steps_u32(dist, p.res);
+    const double ts = (double)(lane + 1) / (double)nsteps;  // lane s-1 holds s / nsteps
+    work.t[lane] = ts;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { work.q_near[k] = q_near[k]; work.q_new[k] = q_new[k]; }
+        work.nearest = nearest;
+        work.nsteps = nsteps;
+        work.mode = 0;
+    }
+}
+
+template <int DIM, int S, bool STAMP>
 __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) {
     constexpr int D = DIM;
     const uint32_t prob = blockIdx.x;
@@ -91,7 +135,10 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
     __shared__ uint32_t rng_buf[16][64];
     __shared__ WavePub<DIM> pub[kResWaves];
     __shared__ WaveExact<DIM> epub[kResWaves];
+    __shared__ QRec<DIM> qrec[2];
+    __shared__ Work<DIM> work;
     __shared__ uint32_t bad_flag[2];
+    __shared__ uint64_t arrive[kResWaves];
 
     ProblemState st = p.state[prob];
     if (p.stop_at_goal && st.goal_node >= 0) return;
@@ -115,22 +162,43 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
 #pragma unroll
         for (int k = 0; k < DIM; ++k) tr[k][s] = (i < n) ? tree[(size_t)k * cap + i] : __builtin_inf();
     }
+    uint64_t wave_arr = 0;  // diagnostic: sum of this wave's (arrival at barrier 1 - release of barrier 3)
+    uint64_t t_rel = 0;
 
+    // the resolver (wave 0) owns the RNG window and samples one query ahead
     RngWindow rng;
     rng.init(rng_buf, p.seed, p.first_problem_id + prob, st.draws);
+    uint64_t draws_done = st.draws;
     if (tid < 2) bad_flag[tid] = 0;
+    if (wave == 0 && p.budget > 0) {
+        double q0[D];
+        sample_state<D, false>(rng, p, DIM, goal_c, q0);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) qrec[0].q[k] = q0[k];
+            qrec[0].pos_after = rng.pos;
+        }
+    }
     __syncthreads();
+
+    uint64_t t_scan = 0, t_b1 = 0, t_res = 0, t_b2 = 0, t_mot = 0, t_b3 = 0, t_ins = 0, t_mark = 0;
+#define OXHIP_STAMP(acc)                                   \
+    if (STAMP) {                                           \
+        uint64_t now_ = (uint64_t)clock64();               \
+        acc += now_ - t_mark;                              \
+        t_mark = now_;                                     \
+    }
+    if (STAMP) { t_mark = (uint64_t)clock64(); t_rel = t_mark; }
 
     uint32_t par = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
     for (uint64_t it = 0; it < p.budget; ++it, par ^= 1) {
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
 
-        // 2. sample (rrt.rs:177-184): every wave derives the same q from the LDS word window
+        // ---- phase A (all waves): scan the register tree for this iteration's query
         double q[D];
-        sample_state<D>(rng, p, DIM, goal_c, q);
-
-        // 3. nearest neighbour (rrt.rs:187-196) over the register tree
+#pragma unroll
+        for (int k = 0; k < D; ++k) q[k] = qrec[par].q[k];
         const uint32_t nslots = uni((n + kResThreads - 1) / kResThreads);
         Best best = best_init();
 #pragma unroll
@@ -163,12 +231,13 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
                 pub[wave] = w;
             }
         }
+        if (STAMP) wave_arr += (uint64_t)clock64() - t_rel;
+        OXHIP_STAMP(t_scan)
         __syncthreads();
+        OXHIP_STAMP(t_b1)
 
-        uint32_t nearest;
-        double min_dist;
-        double q_near[D];
-        {
+        // ---- phase B (wave 0 only): nearest over the 16 candidates, steer, step count, next sample
+        if (wave == 0) {
             const bool in = lane < kResWaves;
             const double pb = in ? pub[in ? lane : 0].b1 : __builtin_inf();
             const uint32_t pamb = in ? pub[in ? lane : 0].amb : 0u;
@@ -178,75 +247,75 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
             const double bnd = bound3(g);
             const bool amb = (__popcll(m2) > 1) || (__ballot(in && (pamb != 0 || ((int)lane != ww && pb <= bnd))) != 0);
             if (!amb) {
-                nearest = pub[ww].i1;
-                min_dist = sqrt(g);
+                double q_near[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) q_near[k] = pub[ww].c[k];
-            } else {
-                // rare: post-sqrt compare with lowest-index ties, exactly as the reference
-                Exact e{__builtin_inf(), 0xFFFFFFFFu};
+                resolve_tail<DIM>(p, lane, pub[ww].i1, sqrt(g), q_near, q, work);
+            } else if (lane == 0) {
+                work.mode = 1;
+            }
+        }
+        __syncthreads();
+        if (uni(work.mode) != 0) {
+            // rare: two d2 within 3 ulps -> post-sqrt compare with lowest-index ties, as the reference
+            Exact e{__builtin_inf(), 0xFFFFFFFFu};
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if ((uint32_t)s < nslots) {
-                        double c[D];
+            for (int s = 0; s < S; ++s) {
+                if ((uint32_t)s < nslots) {
+                    double c[D];
 #pragma unroll
-                        for (int k = 0; k < D; ++k) c[k] = tr[k][s];
-                        double d = sqrt(dist2<D>(c, q, DIM));
-                        if (d < e.dist) { e.dist = d; e.idx = tid + kResThreads * s; }
-                    }
+                    for (int k = 0; k < D; ++k) c[k] = tr[k][s];
+                    double d = sqrt(dist2<D>(c, q, DIM));
+                    if (d < e.dist) { e.dist = d; e.idx = tid + kResThreads * s; }
                 }
-                e = exact_wave_reduce(e);
-                const uint32_t eidx = uni(e.idx);
-                double c[D], cw[D];
-                fetch_slot<DIM, S>(tr, eidx >> 10, c);
-                const int owner = (int)(eidx & 63u);
+            }
+            e = exact_wave_reduce(e);
+            const uint32_t eidx = uni(e.idx);
+            double c[D], cw[D];
+            fetch_slot<DIM, S>(tr, eidx >> 10, c);
+            const int owner = (int)(eidx & 63u);
 #pragma unroll
-                for (int k = 0; k < D; ++k) cw[k] = readlane_f64(c[k], owner);
-                if (lane == 0) {
-                    WaveExact<DIM> w;
-                    w.dist = unid(e.dist); w.idx = eidx; w.pad = 0;
+            for (int k = 0; k < D; ++k) cw[k] = readlane_f64(c[k], owner);
+            if (lane == 0) {
+                WaveExact<DIM> w;
+                w.dist = unid(e.dist); w.idx = eidx; w.pad = 0;
 #pragma unroll
-                    for (int k = 0; k < D; ++k) w.c[k] = cw[k];
-                    epub[wave] = w;
-                }
-                __syncthreads();
+                for (int k = 0; k < D; ++k) w.c[k] = cw[k];
+                epub[wave] = w;
+            }
+            __syncthreads();
+            if (wave == 0) {
                 int bw = 0;
                 Exact be{epub[0].dist, epub[0].idx};
                 for (int w = 1; w < kResWaves; ++w) {
                     Exact o{epub[w].dist, epub[w].idx};
                     if ((o.dist < be.dist) || (o.dist == be.dist && o.idx < be.idx)) { be = o; bw = w; }
                 }
-                nearest = be.idx;
-                min_dist = be.dist;
+                bw = (int)uni((uint32_t)bw);
+                double q_near[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) q_near[k] = epub[bw].c[k];
+                resolve_tail<DIM>(p, lane, uni(be.idx), unid(be.dist), q_near, q, work);
             }
+            __syncthreads();
         }
-        nearest = uni(nearest);
+        OXHIP_STAMP(t_res)
 
-        // 4. steer (rrt.rs:199-208)
-        double q_new[D];
-        if (min_dist > p.max_distance) {
-            double t = p.max_distance / min_dist;
-            lerp<D>(q_near, q, t, q_new, DIM);
-        } else {
+        // ---- phase C: check_motion (rrt.rs:90-116), one interpolated state per wave, one obstacle per lane;
+        //      meanwhile the resolver samples the next query (rrt.rs:177-184)
+        double q_near[D], q_new[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) q_new[k] = q[k];
-        }
-
-        // 5. check_motion (rrt.rs:90-116): interpolated states striped over the 16 waves,
-        //    obstacles over the lanes
+        for (int k = 0; k < D; ++k) { q_near[k] = work.q_near[k]; q_new[k] = work.q_new[k]; }
+        const uint32_t nsteps = uni(work.nsteps);
         bool bad = false;
         if (nobs > 0) {
-            const double dist = sqrt(dist2<D>(q_near, q_new, DIM));
-            const uint32_t nsteps = num_steps_u32(dist, p.res);
             if (nsteps <= 1) {
-                if (wave == 0)
+                if (wave == 1)
                     for (uint32_t j = lane; j < nobs; j += 64) bad = bad || obstacle_hit<D>(p, DIM, q_new, j);
             } else {
-                const double dn = (double)nsteps;
-                for (uint32_t s = wave + 1; s <= nsteps; s += kResWaves) {
-                    const double t = (double)s / dn;
+                // waves 1..15 take the states (wave 0 is busy sampling); wave 0 joins only for long motions
+                for (uint32_t s = (wave == 0 ? kResWaves : wave); s <= nsteps; s += kResWaves) {
+                    const double t = (s <= 64) ? work.t[s - 1] : ((double)s / (double)nsteps);
                     double x[D];
                     lerp<D>(q_near, q_new, t, x, DIM);
                     for (uint32_t j = lane; j < nobs; j += 64) bad = bad || obstacle_hit<D>(p, DIM, x, j);
@@ -254,19 +323,35 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
             }
         }
         if (__ballot(bad) != 0 && lane == 0) bad_flag[par] = 1;
-        if (tid == 0) bad_flag[par ^ 1] = 0;  // re-arm the other parity for the next iteration
+        if (wave == 0) {
+            if (lane == 0) bad_flag[par ^ 1] = 0;  // re-arm the other parity for the next iteration
+            if (it + 1 < p.budget) {
+                double qn[D];
+                sample_state<D, false>(rng, p, DIM, goal_c, qn);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) qrec[par ^ 1].q[k] = qn[k];
+                    qrec[par ^ 1].pos_after = rng.pos;
+                }
+            }
+        }
+        OXHIP_STAMP(t_mot)
         __syncthreads();
-        const bool ok = bad_flag[par] == 0;
+        if (STAMP) t_rel = (uint64_t)clock64();
+        OXHIP_STAMP(t_b3)
 
+        // ---- phase D (all waves): verdict, insert into the owner's registers, goal test
+        const bool ok = bad_flag[par] == 0;
+        const uint32_t nearest = uni(work.nearest);
+        draws_done = qrec[par].pos_after;
         if (wave == 0) {  // bookkeeping is only ever read back from thread 0
             uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
 #pragma unroll
-            for (int k = 0; k < D; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(q_new[k]));
+            for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(q_new[k])));
             st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
             st.iterations++;
             if (ok) st.accepted++;
         }
-
         bool hit = false;
         if (ok && !p.freeze) {
             // 6. insert (rrt.rs:213-217): the owner thread takes the node into its registers
@@ -291,14 +376,21 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
                 hit = true;
             }
         }
+        OXHIP_STAMP(t_ins)
         if (hit && p.stop_at_goal) { stop = 0; break; }
     }
+#undef OXHIP_STAMP
 
+    if (STAMP && p.dbg && prob == 0 && lane == 0) p.dbg[16 + wave] = wave_arr;
     if (tid == 0) {
         st.n_nodes = n;
-        st.draws = rng.pos;
+        st.draws = draws_done;
         st.stop_reason = stop;
         p.state[prob] = st;
+        if (STAMP && p.dbg && prob == 0) {
+            p.dbg[0] = t_scan; p.dbg[1] = t_b1; p.dbg[2] = t_res; p.dbg[3] = t_b2; p.dbg[4] = t_mot;
+            p.dbg[5] = t_b3; p.dbg[6] = t_ins; p.dbg[7] = st.iterations;
+        }
     }
 }
 
@@ -316,7 +408,11 @@ bool resident_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim ==
 void launch_rrt_resident(const DevParams& p, hipStream_t stream) {
     dim3 grid(p.n_problems), block(kResThreads);
     const int s = pick_slots(p.cap);
-#define OXHIP_LAUNCH(DIM_, S_) hipLaunchKernelGGL((rrt_resident_kernel<DIM_, S_>), grid, block, 0, stream, p)
+#define OXHIP_LAUNCH(DIM_, S_)                                                                              \
+    do {                                                                                                    \
+        if (p.dbg) hipLaunchKernelGGL((rrt_resident_kernel<DIM_, S_, true>), grid, block, 0, stream, p);    \
+        else hipLaunchKernelGGL((rrt_resident_kernel<DIM_, S_, false>), grid, block, 0, stream, p);         \
+    } while (0)
     if (p.dim == 3) {
         if (s == 2) OXHIP_LAUNCH(3, 2); else if (s == 4) OXHIP_LAUNCH(3, 4); else OXHIP_LAUNCH(3, 10);
     } else {
