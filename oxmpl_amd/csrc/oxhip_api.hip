@@ -115,7 +115,9 @@ struct oxhip_rrt_batch {
     DevParams dp{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf<double> tree, goal_c, goal_thr, sph_c, sph_thr, box_lo, box_hi;
+    DevBuf<double> tree, goal_c, goal_thr, sph_c, sph_thr, sph_filt, box_lo, box_hi;
+    std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
+    bool filt_dirty = true;
     DevBuf<int32_t> parent;
     DevBuf<ProblemState> state;
     DevBuf<uint64_t> dbg;
@@ -216,6 +218,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.seed = cfg->seed;
     dp.first_problem_id = cfg->first_problem_id;
     dp.stop_at_goal = cfg->stop_at_goal ? 1 : 0;
+    dp.t_steer = sqrt_le_threshold(cfg->max_distance);
 
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -283,6 +286,9 @@ int32_t oxhip_rrt_batch_set_spheres(oxhip_rrt_batch* b, const double* centres, c
     if ((st = upload(b->sph_c, c, b->stream)) != OXHIP_OK) return st;
     if ((st = upload(b->sph_thr, thr, b->stream)) != OXHIP_OK) return st;
     b->dp.n_spheres = n; b->dp.sph_c = b->sph_c.p; b->dp.sph_thr = b->sph_thr.p;
+    b->sph_centres.assign(centres, centres + (size_t)n * dim);
+    b->sph_radii.assign(radii, radii + n);
+    b->filt_dirty = true;
     return OXHIP_OK;
 }
 
@@ -313,6 +319,7 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
         if (!(std::fabs(starts[i]) <= kMaxMagnitude) || !(std::fabs(goal_centres[i]) <= kMaxMagnitude))
             return fail(OXHIP_ERR_BAD_ARG, "start / goal centre not finite or beyond 1e150");
     b->starts.assign(starts, starts + (size_t)P * dim);
+    b->filt_dirty = true;
     std::vector<double> thr(P);
     for (uint32_t p = 0; p < P; ++p) thr[p] = sqrt_le_threshold(goal_radii[p]);
     std::vector<ProblemState> states(P);
@@ -339,6 +346,33 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
     return OXHIP_OK;
 }
 
+// Conservative midpoint filter of the resident kernel's motion check.  Every state the check
+// interpolates lies within max_distance/2 (+ rounding) of the segment midpoint, so
+// d2(centre, mid) > (r + h)^2 proves sphere (centre, r) valid for the whole motion.  h carries a
+// relative 1e-6 and an absolute 1e-9 * (largest coordinate magnitude) margin, orders of magnitude
+// above the few-ulp rounding of the interpolation; the filter never decides a motion invalid.
+static int32_t refresh_filter(oxhip_rrt_batch* b) {
+    if (!b->filt_dirty) return OXHIP_OK;
+    const uint32_t n = b->dp.n_spheres, dim = b->cfg.dim;
+    double maxabs = 1.0;
+    for (uint32_t k = 0; k < 2 * dim; ++k) maxabs = std::fmax(maxabs, std::fabs(b->cfg.bounds[k]));
+    for (double v : b->starts) maxabs = std::fmax(maxabs, std::fabs(v));
+    for (double v : b->sph_centres) maxabs = std::fmax(maxabs, std::fabs(v));
+    const double h = 0.5 * b->cfg.max_distance * (1.0 + 1e-6) + 1e-9 * maxabs;
+    std::vector<double> f(n);
+    for (uint32_t j = 0; j < n; ++j) {
+        const double r = b->sph_radii[j];
+        if (std::isnan(r) || std::isinf(r)) f[j] = r < 0.0 ? -1.0 : std::numeric_limits<double>::infinity();
+        else if (r < 0.0) f[j] = -1.0;                       // distance > negative radius always holds
+        else f[j] = (r + h) * (r + h) * (1.0 + 1e-9);
+    }
+    int32_t st = upload(b->sph_filt, f, b->stream);
+    if (st != OXHIP_OK) return st;
+    b->dp.sph_filt = b->sph_filt.p;
+    b->filt_dirty = false;
+    return OXHIP_OK;
+}
+
 static int32_t read_states(oxhip_rrt_batch* b, std::vector<ProblemState>& states) {
     states.resize(b->cfg.n_problems);
     HIP_TRY(hipMemcpyAsync(states.data(), b->state.p, states.size() * sizeof(ProblemState), hipMemcpyDeviceToHost, b->stream));
@@ -352,6 +386,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
     if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");  // rrt.rs:160-163
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
+    if ((st = refresh_filter(b)) != OXHIP_OK) return st;
     const bool has_timeout = timeout_s > 0.0 && std::isfinite(timeout_s);
     const auto t0 = std::chrono::steady_clock::now();
     // with a timeout the budget is cut into chunks so the host clock is consulted in between

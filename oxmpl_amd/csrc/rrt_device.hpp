@@ -55,6 +55,8 @@ struct DevParams {
     ProblemState* state;    // [P]
     const double* goal_c;   // [P][dim]
     const double* goal_thr; // [P]  satisfied iff d2 <= thr (== sqrt(d2) <= radius, exactly)
+    double t_steer;         // largest d2 with sqrt(d2) <= max_distance: steer iff d2 > t_steer (exact)
+    const double* sph_filt; // [n_spheres] conservative filter: d2(centre, segment midpoint) > filt => sphere cannot be hit
     uint64_t* dbg;          // optional [16] cycle stamps of workgroup 0 (diagnostic build of the resident kernel)
 };
 
@@ -115,11 +117,12 @@ struct RngWindow {
         if (blk - base_blk >= 64) {  // workgroup-uniform
             if (WG_SYNC) __syncthreads();  // everybody is done reading the old window
             base_blk = blk;
-            if (threadIdx.x < 64) {
+            if (!WG_SYNC || threadIdx.x < 64) {  // WG_SYNC: wave 0 refills; otherwise the owning wave does
+                const uint32_t bl = threadIdx.x & 63;
                 uint32_t o[16];
-                chacha12_block(seed, blk + threadIdx.x, stream, o);
+                chacha12_block(seed, blk + bl, stream, o);
 #pragma unroll
-                for (int w = 0; w < 16; ++w) buf[w][threadIdx.x] = o[w];
+                for (int w = 0; w < 16; ++w) buf[w][bl] = o[w];
             }
             if (WG_SYNC) __syncthreads();
         }

@@ -52,12 +52,35 @@ __device__ __forceinline__ double bound3(double g) {
     return __longlong_as_double((long long)((uint64_t)__double_as_longlong(g) + 3));
 }
 
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)__double2hiint(v); }
+
+// Per-lane scan state.  d2 >= +0, so the high dword orders like the value: h2 tracks the second
+// smallest HIGH DWORD (with multiplicity) in one v_med3_u32 per node.  Two d2 whose square roots
+// could coincide differ by <= 3 ulps, hence their high dwords differ by <= 1: `h2 <= hi(b1) + 1`
+// is a conservative (never missing, ~1e-6 false-positive) near-tie detector.
+struct Scan {
+    double b1;      // smallest d2 of this lane
+    uint32_t slot;  // its slot (lowest index: slots are visited in increasing index order)
+    uint32_t h2;    // second smallest high dword
+};
+__device__ __forceinline__ void scan_push(Scan& v, double d, uint32_t s) {
+    v.h2 = umed3(hi32(d), hi32(v.b1), v.h2);
+    const bool lt = d < v.b1;  // strict: the earlier (lower) index keeps exact ties
+    v.b1 = lt ? d : v.b1;
+    v.slot = lt ? s : v.slot;
+}
+
 template <int DIM>
 struct WavePub {      // one wave's nearest-neighbour candidate
     double b1;        // its smallest d2
     uint32_t i1;      // lowest index attaining it
-    uint32_t amb;     // the wave saw another d2 within 3 ulps of b1
-    double c[DIM];    // the candidate's coordinates
+    uint32_t amb;     // the wave saw another d2 whose high dword is within 1 of b1's
+    double c[DIM];    // the candidate's coordinates (written by the owning lane)
 };
 template <int DIM>
 struct WaveExact {
@@ -67,60 +90,95 @@ struct WaveExact {
     double c[DIM];
 };
 
-// static-index fetch of slot `slot` (wave-uniform) from the register tree
-template <int DIM, int S>
-__device__ __forceinline__ void fetch_slot(const double (&tr)[DIM][S], uint32_t slot, double c[DIM]) {
-#pragma unroll
-    for (int k = 0; k < DIM; ++k) c[k] = 0.0;
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (slot == (uint32_t)s) {  // uniform branch; every index below is a compile-time constant
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) c[k] = tr[k][s];
-        }
-    }
-}
-
-// next query, written by the resolver one iteration ahead
+// next query, written by the sampler wave one iteration ahead
 template <int DIM>
 struct QRec {
     double q[DIM];
     uint64_t pos_after;  // stream position after this query's draws
 };
 
-// what the resolver hands to the motion-check waves and to the insert step
+// the resolver's verdict for the insert step
 template <int DIM>
 struct Work {
-    double q_near[DIM];
     double q_new[DIM];
     uint32_t nearest;
-    uint32_t nsteps;
+    uint32_t ok;
     uint32_t mode;   // 0 = resolved, 1 = exact re-scan requested
     uint32_t pad;
-    double t[64];    // t[s-1] = s / nsteps for s <= 64 (one f64 division per lane, in parallel)
 };
 
-// steer (rrt.rs:199-208) + the scalar part of check_motion (rrt.rs:95-97,105); resolver wave only
+// lane-predicated store of the owning lane's slot `slot` (wave-uniform) into LDS
+template <int DIM, int S>
+__device__ __forceinline__ void store_slot(const double (&tr)[DIM][S], uint32_t slot, bool mine, double* dst) {
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (slot == (uint32_t)s) {  // uniform branch; indices below are compile-time constants
+            if (mine) {
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) dst[k] = tr[k][s];
+            }
+        }
+    }
+}
+
+// steer (rrt.rs:199-208) + check_motion (rrt.rs:90-116) by the resolver wave: one obstacle per
+// lane from the LDS table.  A conservative midpoint filter settles most motions with a single
+// distance per sphere: every interpolated state lies within max_distance/2 of the segment
+// midpoint, so d2(centre, mid) > (r + max_distance/2 + margin)^2 proves the sphere cannot be hit.
+// Only if some sphere fails the filter are the interpolated states tested, exactly as the
+// reference does (the verdict is identical either way; the filter only skips provably valid work).
 template <int DIM>
-__device__ __forceinline__ void resolve_tail(const DevParams& p, uint32_t lane, uint32_t nearest, double min_dist,
-                                             const double q_near[DIM], const double q[DIM], Work<DIM>& work) {
+__device__ __forceinline__ void resolve_tail(const DevParams& p, uint32_t lane, uint32_t nearest, bool have_dist,
+                                             double g_or_dist, const double q_near[DIM], const double q[DIM],
+                                             const double (*obs)[64], uint32_t ns64, Work<DIM>& work) {
     double q_new[DIM];
-    if (min_dist > p.max_distance) {
-        double t = p.max_distance / min_dist;
+    const bool far = have_dist ? (g_or_dist > p.max_distance) : (g_or_dist > p.t_steer);
+    if (far) {
+        const double md = have_dist ? g_or_dist : sqrt(g_or_dist);
+        const double t = p.max_distance / md;
         lerp<DIM>(q_near, q, t, q_new, DIM);
     } else {
 #pragma unroll
         for (int k = 0; k < DIM; ++k) q_new[k] = q[k];
     }
-    const double dist = sqrt(dist2<DIM>(q_near, q_new, DIM));
-    const uint32_t nsteps = num_steps_u32(dist, p.res);
-    const double ts = (double)(lane + 1) / (double)nsteps;  // lane s-1 holds s / nsteps
-    work.t[lane] = ts;
+    const uint32_t nobs = p.n_spheres + p.n_boxes;
+    bool ok = true;
+    if (nobs > 0) {
+        double c[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) c[k] = obs[k][lane];
+        const double thr = obs[DIM][lane], filt = obs[DIM + 1][lane];
+        double mid[DIM];
+        lerp<DIM>(q_near, q_new, 0.5, mid, DIM);
+        const bool maybe = !(dist2<DIM>(c, mid, DIM) > filt);
+        const bool extras = nobs > ns64;  // spheres beyond the first 64 and every box: always stepped
+        if (__ballot(maybe) != 0 || extras) {
+            const double dist = sqrt(dist2<DIM>(q_near, q_new, DIM));
+            const uint32_t nsteps = num_steps_u32(dist, p.res);
+            bool bad = false;
+            if (nsteps <= 1) {
+                bad = !(dist2<DIM>(c, q_new, DIM) > thr);
+                for (uint32_t j = ns64 + lane; j < nobs; j += 64) bad = bad || obstacle_hit<DIM>(p, DIM, q_new, j);
+            } else {
+                const double dn = (double)nsteps;
+                const double tl = (double)(lane + 1) / dn;  // lane s-1 holds s / nsteps (one division, all lanes)
+                for (uint32_t s = 1; s <= nsteps; ++s) {
+                    const double t = (s <= 64) ? readlane_f64(tl, (int)(s - 1)) : ((double)s / dn);
+                    double x[DIM];
+                    lerp<DIM>(q_near, q_new, t, x, DIM);
+                    bad = bad || !(dist2<DIM>(c, x, DIM) > thr);
+                    for (uint32_t j = ns64 + lane; j < nobs; j += 64) bad = bad || obstacle_hit<DIM>(p, DIM, x, j);
+                    if (__ballot(bad) != 0) break;  // the reference also stops at the first invalid state
+                }
+            }
+            ok = __ballot(bad) == 0;
+        }
+    }
     if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) { work.q_near[k] = q_near[k]; work.q_new[k] = q_new[k]; }
+        for (int k = 0; k < DIM; ++k) work.q_new[k] = q_new[k];
         work.nearest = nearest;
-        work.nsteps = nsteps;
+        work.ok = ok ? 1u : 0u;
         work.mode = 0;
     }
 }
@@ -128,6 +186,7 @@ __device__ __forceinline__ void resolve_tail(const DevParams& p, uint32_t lane, 
 template <int DIM, int S, bool STAMP>
 __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) {
     constexpr int D = DIM;
+    constexpr uint32_t kResolver = 0, kSampler = kResWaves - 1;
     const uint32_t prob = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = uni(tid >> 6), lane = tid & 63;
@@ -137,8 +196,7 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
     __shared__ WaveExact<DIM> epub[kResWaves];
     __shared__ QRec<DIM> qrec[2];
     __shared__ Work<DIM> work;
-    __shared__ uint32_t bad_flag[2];
-    __shared__ uint64_t arrive[kResWaves];
+    __shared__ double obs[DIM + 2][64];  // first 64 spheres: centre, validity threshold, filter threshold
 
     ProblemState st = p.state[prob];
     if (p.stop_at_goal && st.goal_node >= 0) return;
@@ -150,7 +208,7 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
 #pragma unroll
     for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
     const double goal_thr = p.goal_thr[prob];
-    const uint32_t nobs = p.n_spheres + p.n_boxes;
+    const uint32_t ns64 = p.n_spheres < 64 ? p.n_spheres : 64;
 
     uint32_t n = st.n_nodes;
 
@@ -162,15 +220,18 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
 #pragma unroll
         for (int k = 0; k < DIM; ++k) tr[k][s] = (i < n) ? tree[(size_t)k * cap + i] : __builtin_inf();
     }
-    uint64_t wave_arr = 0;  // diagnostic: sum of this wave's (arrival at barrier 1 - release of barrier 3)
-    uint64_t t_rel = 0;
+    if (tid < 64) {  // unused lanes hold a sphere that can never be hit
+#pragma unroll
+        for (int k = 0; k < D; ++k) obs[k][tid] = tid < ns64 ? p.sph_c[(size_t)k * p.n_spheres + tid] : 0.0;
+        obs[D][tid] = tid < ns64 ? p.sph_thr[tid] : -1.0;
+        obs[D + 1][tid] = tid < ns64 ? p.sph_filt[tid] : -1.0;
+    }
 
-    // the resolver (wave 0) owns the RNG window and samples one query ahead
+    // the sampler wave owns the RNG window and works one query ahead (rrt.rs:177-184)
     RngWindow rng;
     rng.init(rng_buf, p.seed, p.first_problem_id + prob, st.draws);
     uint64_t draws_done = st.draws;
-    if (tid < 2) bad_flag[tid] = 0;
-    if (wave == 0 && p.budget > 0) {
+    if (wave == kSampler && p.budget > 0) {
         double q0[D];
         sample_state<D, false>(rng, p, DIM, goal_c, q0);
         if (lane == 0) {
@@ -181,7 +242,7 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
     }
     __syncthreads();
 
-    uint64_t t_scan = 0, t_b1 = 0, t_res = 0, t_b2 = 0, t_mot = 0, t_b3 = 0, t_ins = 0, t_mark = 0;
+    uint64_t t_scan = 0, t_b1 = 0, t_res = 0, t_b2 = 0, t_ins = 0, t_mark = 0, wave_arr = 0, t_rel = 0;
 #define OXHIP_STAMP(acc)                                   \
     if (STAMP) {                                           \
         uint64_t now_ = (uint64_t)clock64();               \
@@ -195,40 +256,34 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
     for (uint64_t it = 0; it < p.budget; ++it, par ^= 1) {
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
 
-        // ---- phase A (all waves): scan the register tree for this iteration's query
+        // ---- phase A (all waves): scan the register tree for this iteration's query (rrt.rs:187-196)
         double q[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) q[k] = qrec[par].q[k];
         const uint32_t nslots = uni((n + kResThreads - 1) / kResThreads);
-        Best best = best_init();
+        Scan sc{__builtin_inf(), 0u, 0xFFFFFFFFu};
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             if ((uint32_t)s < nslots) {
                 double c[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) c[k] = tr[k][s];
-                best_push(best, dist2<D>(c, q, DIM), tid + kResThreads * s);
+                scan_push(sc, dist2<D>(c, q, DIM), (uint32_t)s);
             }
         }
         {
-            const double wmin = wave_min_f64(best.b1);
-            const uint64_t eqm = __ballot(best.b1 == wmin);
+            const double wmin = wave_min_f64(sc.b1);
+            const uint64_t eqm = __ballot(sc.b1 == wmin);
             const int wl = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
-            const uint32_t widx = __builtin_amdgcn_readlane(best.i1, wl);
-            const double bnd = bound3(wmin);
-            const bool amb_l = ((int)lane != wl && best.b1 <= bnd) || (best.b2 <= bnd);
+            const uint32_t wslot = __builtin_amdgcn_readlane(sc.slot, wl);
+            const uint32_t hb = hi32(wmin) + 1;
+            const bool amb_l = ((int)lane != wl && hi32(sc.b1) <= hb) || (sc.h2 <= hb);
             const uint32_t wamb = __ballot(amb_l) != 0 ? 1u : 0u;
-            double c[D], cw[D];
-            fetch_slot<DIM, S>(tr, widx >> 10, c);
-            // readlanes stay outside the lane-0 branch so lane wl's registers are live there
-#pragma unroll
-            for (int k = 0; k < D; ++k) cw[k] = readlane_f64(c[k], wl);
+            store_slot<DIM, S>(tr, wslot, (int)lane == wl, pub[wave].c);
             if (lane == 0) {
-                WavePub<DIM> w;
-                w.b1 = wmin; w.i1 = widx; w.amb = wamb;
-#pragma unroll
-                for (int k = 0; k < D; ++k) w.c[k] = cw[k];
-                pub[wave] = w;
+                pub[wave].b1 = wmin;
+                pub[wave].i1 = (wave << 6) + (uint32_t)wl + (wslot << 10);
+                pub[wave].amb = wamb;
             }
         }
         if (STAMP) wave_arr += (uint64_t)clock64() - t_rel;
@@ -236,28 +291,41 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
         __syncthreads();
         OXHIP_STAMP(t_b1)
 
-        // ---- phase B (wave 0 only): nearest over the 16 candidates, steer, step count, next sample
-        if (wave == 0) {
+        // ---- phase B: wave 0 resolves (nearest over 16 candidates, steer, motion check);
+        //      wave 15 samples the next query meanwhile; the others wait
+        if (wave == kResolver) {
             const bool in = lane < kResWaves;
             const double pb = in ? pub[in ? lane : 0].b1 : __builtin_inf();
             const uint32_t pamb = in ? pub[in ? lane : 0].amb : 0u;
             const double g = wave_min_f64(pb);
             const uint64_t m2 = __ballot(in && pb == g);
             const int ww = m2 ? (__ffsll((unsigned long long)m2) - 1) : 0;
-            const double bnd = bound3(g);
-            const bool amb = (__popcll(m2) > 1) || (__ballot(in && (pamb != 0 || ((int)lane != ww && pb <= bnd))) != 0);
+            const uint32_t hb = hi32(g) + 1;
+            const bool amb = (__popcll(m2) > 1) || (__ballot(in && (pamb != 0 || ((int)lane != ww && hi32(pb) <= hb))) != 0);
             if (!amb) {
                 double q_near[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) q_near[k] = pub[ww].c[k];
-                resolve_tail<DIM>(p, lane, pub[ww].i1, sqrt(g), q_near, q, work);
+                resolve_tail<DIM>(p, lane, pub[ww].i1, false, g, q_near, q, obs, ns64, work);
             } else if (lane == 0) {
                 work.mode = 1;
             }
+        } else if (wave == kSampler) {
+            if (it + 1 < p.budget) {
+                double qn[D];
+                sample_state<D, false>(rng, p, DIM, goal_c, qn);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) qrec[par ^ 1].q[k] = qn[k];
+                    qrec[par ^ 1].pos_after = rng.pos;
+                }
+            }
         }
+        OXHIP_STAMP(t_res)
         __syncthreads();
         if (uni(work.mode) != 0) {
-            // rare: two d2 within 3 ulps -> post-sqrt compare with lowest-index ties, as the reference
+            // rare: two d2 with (nearly) equal high dwords -> post-sqrt compare with lowest-index ties,
+            // literally as the reference does
             Exact e{__builtin_inf(), 0xFFFFFFFFu};
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -271,20 +339,13 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
             }
             e = exact_wave_reduce(e);
             const uint32_t eidx = uni(e.idx);
-            double c[D], cw[D];
-            fetch_slot<DIM, S>(tr, eidx >> 10, c);
-            const int owner = (int)(eidx & 63u);
-#pragma unroll
-            for (int k = 0; k < D; ++k) cw[k] = readlane_f64(c[k], owner);
+            store_slot<DIM, S>(tr, eidx >> 10, lane == (eidx & 63u), epub[wave].c);
             if (lane == 0) {
-                WaveExact<DIM> w;
-                w.dist = unid(e.dist); w.idx = eidx; w.pad = 0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) w.c[k] = cw[k];
-                epub[wave] = w;
+                epub[wave].dist = unid(e.dist);
+                epub[wave].idx = eidx;
             }
             __syncthreads();
-            if (wave == 0) {
+            if (wave == kResolver) {
                 int bw = 0;
                 Exact be{epub[0].dist, epub[0].idx};
                 for (int w = 1; w < kResWaves; ++w) {
@@ -295,54 +356,19 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
                 double q_near[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) q_near[k] = epub[bw].c[k];
-                resolve_tail<DIM>(p, lane, uni(be.idx), unid(be.dist), q_near, q, work);
+                resolve_tail<DIM>(p, lane, uni(be.idx), true, unid(be.dist), q_near, q, obs, ns64, work);
             }
             __syncthreads();
         }
-        OXHIP_STAMP(t_res)
-
-        // ---- phase C: check_motion (rrt.rs:90-116), one interpolated state per wave, one obstacle per lane;
-        //      meanwhile the resolver samples the next query (rrt.rs:177-184)
-        double q_near[D], q_new[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) { q_near[k] = work.q_near[k]; q_new[k] = work.q_new[k]; }
-        const uint32_t nsteps = uni(work.nsteps);
-        bool bad = false;
-        if (nobs > 0) {
-            if (nsteps <= 1) {
-                if (wave == 1)
-                    for (uint32_t j = lane; j < nobs; j += 64) bad = bad || obstacle_hit<D>(p, DIM, q_new, j);
-            } else {
-                // waves 1..15 take the states (wave 0 is busy sampling); wave 0 joins only for long motions
-                for (uint32_t s = (wave == 0 ? kResWaves : wave); s <= nsteps; s += kResWaves) {
-                    const double t = (s <= 64) ? work.t[s - 1] : ((double)s / (double)nsteps);
-                    double x[D];
-                    lerp<D>(q_near, q_new, t, x, DIM);
-                    for (uint32_t j = lane; j < nobs; j += 64) bad = bad || obstacle_hit<D>(p, DIM, x, j);
-                }
-            }
-        }
-        if (__ballot(bad) != 0 && lane == 0) bad_flag[par] = 1;
-        if (wave == 0) {
-            if (lane == 0) bad_flag[par ^ 1] = 0;  // re-arm the other parity for the next iteration
-            if (it + 1 < p.budget) {
-                double qn[D];
-                sample_state<D, false>(rng, p, DIM, goal_c, qn);
-                if (lane == 0) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) qrec[par ^ 1].q[k] = qn[k];
-                    qrec[par ^ 1].pos_after = rng.pos;
-                }
-            }
-        }
-        OXHIP_STAMP(t_mot)
-        __syncthreads();
         if (STAMP) t_rel = (uint64_t)clock64();
-        OXHIP_STAMP(t_b3)
+        OXHIP_STAMP(t_b2)
 
         // ---- phase D (all waves): verdict, insert into the owner's registers, goal test
-        const bool ok = bad_flag[par] == 0;
+        const bool ok = uni(work.ok) != 0;
         const uint32_t nearest = uni(work.nearest);
+        double q_new[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) q_new[k] = work.q_new[k];
         draws_done = qrec[par].pos_after;
         if (wave == 0) {  // bookkeeping is only ever read back from thread 0
             uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
@@ -388,8 +414,8 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
         st.stop_reason = stop;
         p.state[prob] = st;
         if (STAMP && p.dbg && prob == 0) {
-            p.dbg[0] = t_scan; p.dbg[1] = t_b1; p.dbg[2] = t_res; p.dbg[3] = t_b2; p.dbg[4] = t_mot;
-            p.dbg[5] = t_b3; p.dbg[6] = t_ins; p.dbg[7] = st.iterations;
+            p.dbg[0] = t_scan; p.dbg[1] = t_b1; p.dbg[2] = t_res; p.dbg[3] = t_b2; p.dbg[4] = 0;
+            p.dbg[5] = 0; p.dbg[6] = t_ins; p.dbg[7] = st.iterations;
         }
     }
 }

@@ -15,12 +15,11 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s\n", hipGetErrorString(e_)); return 1; } } while (0)
 
-template <int VAR>
-__global__ __launch_bounds__(1024) void scan_kernel(const double* pts, double* out, int iters) {
-    constexpr int S = 10;
+template <int VAR, int NT = 1024, int S = 10>
+__global__ __launch_bounds__(NT) void scan_kernel(const double* pts, double* out, int iters) {
     double tr[3][S];
     for (int s = 0; s < S; ++s)
-        for (int k = 0; k < 3; ++k) tr[k][s] = pts[(size_t)(threadIdx.x + 1024 * s) * 3 + k];
+        for (int k = 0; k < 3; ++k) tr[k][s] = pts[(size_t)((threadIdx.x + NT * s) % 10240) * 3 + k];
     double q[3] = {5.0 + 1e-3 * blockIdx.x, 5.0, 5.0};
     double accd = 0.0; uint32_t acci = 0;
     uint64_t t0 = clock64();
@@ -80,18 +79,18 @@ __global__ __launch_bounds__(1024) void scan_kernel(const double* pts, double* o
         }
     }
     uint64_t t1 = clock64();
-    out[blockIdx.x * 1024 + threadIdx.x] = accd + acci;
+    out[blockIdx.x * NT + threadIdx.x] = accd + acci;
     if (threadIdx.x == 0 && blockIdx.x == 0) ((uint64_t*)out)[1 << 20] = t1 - t0;
 }
 
-template <int VAR>
+template <int VAR, int NT = 1024, int S = 10>
 int run(const char* name, const double* pts, double* out) {
     int iters = 20000;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    scan_kernel<VAR><<<256, 1024>>>(pts, out, 200);
+    scan_kernel<VAR, NT, S><<<256, NT>>>(pts, out, 200);
     CK(hipEventRecord(e0));
-    scan_kernel<VAR><<<256, 1024>>>(pts, out, iters);
+    scan_kernel<VAR, NT, S><<<256, NT>>>(pts, out, iters);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -114,5 +113,9 @@ int main() {
     run<2>("2 b1+slot only", pts, out);
     run<3>("3 pure v_min_f64", pts, out);
     run<4>("4 u64 compare + med3", pts, out);
+    run<1, 768, 14>("1 med3, 768 threads x 14 slots", pts, out);
+    run<1, 512, 20>("1 med3, 512 threads x 20 slots", pts, out);
+    run<1, 256, 40>("1 med3, 256 threads x 40 slots", pts, out);
+    run<3, 512, 20>("3 pure min, 512 threads x 20 slots", pts, out);
     return 0;
 }

@@ -15,7 +15,7 @@ gpu.solve(10 ** 7)
 gpu.enable_stamps(True)
 gpu.solve(iters, freeze=True)
 s = gpu.stamps()
-names = ["scan+publish", "barrier1", "resolve", "-", "motion/sample", "barrier3", "verdict+insert"]
+names = ["scan+publish", "barrier1", "resolve|sample", "barrier2", "-", "-", "verdict+insert"]
 tot = float(sum(int(v) for v in s[:7]))
 print("steady@10k, %d iterations, kernel %.3f ms" % (iters, gpu.last_timing()["kernel_ms"]))
 for nme, v in zip(names, s[:7]):
