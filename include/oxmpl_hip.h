@@ -51,7 +51,8 @@ typedef enum oxhip_stop_reason {
     OXHIP_STOP_GOAL = 0,        /* goal.is_satisfied(q_new) with stop_at_goal      rrt.rs:220-223 */
     OXHIP_STOP_ITERATIONS = 1,  /* iteration budget of this solve call exhausted */
     OXHIP_STOP_NODES = 2,       /* tree reached max_nodes */
-    OXHIP_STOP_TIMEOUT = 3      /* wall-clock timeout between kernel chunks */
+    OXHIP_STOP_TIMEOUT = 3,     /* wall-clock timeout between kernel chunks */
+    OXHIP_STOP_INTERNAL = 4     /* kernel-internal hand-off never completed (bug guard); solve returns OXHIP_ERR_HIP */
 } oxhip_stop_reason;
 
 typedef enum oxhip_kernel_kind {

@@ -119,6 +119,7 @@ struct oxhip_rrt_batch {
     std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
     bool filt_dirty = true;
     DevBuf<int32_t> parent;
+    DevBuf<uint8_t> skip;
     DevBuf<ProblemState> state;
     DevBuf<uint64_t> dbg;
     std::vector<double> starts;  // host copy, [P][dim]
@@ -227,6 +228,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     chk(hipEventCreate(&b->ev1));
     chk(b->tree.alloc((size_t)P * dim * cap));
     chk(b->parent.alloc((size_t)P * cap));
+    chk(b->skip.alloc((size_t)P * cap));
     chk(b->state.alloc(P));
     chk(b->goal_c.alloc((size_t)P * dim));
     chk(b->goal_thr.alloc(P));
@@ -235,7 +237,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         oxhip_rrt_batch_destroy(b);
         return fail(OXHIP_ERR_HIP, msg);
     }
-    dp.tree = b->tree.p; dp.parent = b->parent.p; dp.state = b->state.p;
+    dp.tree = b->tree.p; dp.parent = b->parent.p; dp.skip = b->skip.p; dp.state = b->state.p;
     dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p;
 
     uint32_t kind = cfg->kernel;
@@ -338,6 +340,7 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
     // node 0 of coordinate k of problem p lives at tree[(p*dim + k)*cap]: strided 2-D copy
     HIP_TRY(hipMemcpy2DAsync(b->tree.p, (size_t)cap * sizeof(double), starts, sizeof(double), sizeof(double),
                              (size_t)P * dim, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemsetAsync(b->skip.p, 0, (size_t)P * cap, b->stream));
     std::vector<int32_t> minus1(P, -1);
     HIP_TRY(hipMemcpy2DAsync(b->parent.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
                              sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
@@ -390,7 +393,8 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
     const bool has_timeout = timeout_s > 0.0 && std::isfinite(timeout_s);
     const auto t0 = std::chrono::steady_clock::now();
     // with a timeout the budget is cut into chunks so the host clock is consulted in between
-    const uint64_t chunk = has_timeout ? 2048 : max_iterations;
+    // a launch's budget stays below 2^31 (the pipeline kernel counts queries in 32 bits)
+    const uint64_t chunk = has_timeout ? 2048 : (max_iterations < (1ull << 30) ? max_iterations : (1ull << 30));
     uint64_t remaining = max_iterations;
     b->last_kernel_ms = 0.0;
     b->last_launches = 0;
@@ -422,6 +426,8 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         }
     }
     if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    for (auto& s : states)
+        if (s.stop_reason == OXHIP_STOP_INTERNAL) return fail(OXHIP_ERR_HIP, "resident kernel: scanner/resolver hand-off stalled");
     if (timed_out) {
         for (auto& s : states) if (s.stop_reason == OXHIP_STOP_ITERATIONS) s.stop_reason = OXHIP_STOP_TIMEOUT;
         HIP_TRY(hipMemcpyAsync(b->state.p, states.data(), states.size() * sizeof(ProblemState), hipMemcpyHostToDevice, b->stream));

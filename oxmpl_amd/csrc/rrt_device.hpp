@@ -52,6 +52,7 @@ struct DevParams {
     const double* box_hi;   // [dim][n_boxes]
     double* tree;           // [P][dim][cap]  SoA per problem
     int32_t* parent;        // [P][cap]
+    uint8_t* skip;          // [P][cap] 1 = coordinate duplicate of a lower-index node: never nearest (resident kernel)
     ProblemState* state;    // [P]
     const double* goal_c;   // [P][dim]
     const double* goal_thr; // [P]  satisfied iff d2 <= thr (== sqrt(d2) <= radius, exactly)

@@ -90,23 +90,6 @@ struct WaveExact {
     double c[DIM];
 };
 
-// next query, written by the sampler wave one iteration ahead
-template <int DIM>
-struct QRec {
-    double q[DIM];
-    uint64_t pos_after;  // stream position after this query's draws
-};
-
-// the resolver's verdict for the insert step
-template <int DIM>
-struct Work {
-    double q_new[DIM];
-    uint32_t nearest;
-    uint32_t ok;
-    uint32_t mode;   // 0 = resolved, 1 = exact re-scan requested
-    uint32_t pad;
-};
-
 // lane-predicated store of the owning lane's slot `slot` (wave-uniform) into LDS
 template <int DIM, int S>
 __device__ __forceinline__ void store_slot(const double (&tr)[DIM][S], uint32_t slot, bool mine, double* dst) {
@@ -121,17 +104,82 @@ __device__ __forceinline__ void store_slot(const double (&tr)[DIM][S], uint32_t 
     }
 }
 
-// steer (rrt.rs:199-208) + check_motion (rrt.rs:90-116) by the resolver wave: one obstacle per
-// lane from the LDS table.  A conservative midpoint filter settles most motions with a single
-// distance per sphere: every interpolated state lies within max_distance/2 of the segment
-// midpoint, so d2(centre, mid) > (r + max_distance/2 + margin)^2 proves the sphere cannot be hit.
-// Only if some sphere fails the filter are the interpolated states tested, exactly as the
-// reference does (the verdict is identical either way; the filter only skips provably valid work).
+// ------------------------------------------------------------------------------------------
+// Asynchronous pipeline.  kScanWaves scanner waves own the tree (node i in thread i % 512, slot
+// i / 512) and stream queries from an LDS ring without ever meeting at a workgroup barrier; one
+// resolver wave samples the queries ahead, consumes the scanners' per-query results in order,
+// covers the nodes committed after a scan's snapshot from its own lanes (the last 64 nodes, one
+// per lane), steers, checks the motion and commits.  Sequential semantics are the resolver's:
+// iteration k sees exactly the tree left by iterations < k, as in rrt.rs:170-225.
+// ------------------------------------------------------------------------------------------
+constexpr int kScanWaves = 8;
+constexpr int kScanThreads = kScanWaves * 64;        // 512
+constexpr int kPipeThreads = kScanThreads + 64;      // + the resolver wave
+constexpr int kRing = 16;                            // queries in flight (power of two)
+constexpr uint32_t kNoNode = 0xFFFFFFFFu;
+constexpr uint32_t kMaxSpins = 1u << 22;             // ~0.5 s of polling: turns a protocol bug into an error, not a hang
+
 template <int DIM>
-__device__ __forceinline__ void resolve_tail(const DevParams& p, uint32_t lane, uint32_t nearest, bool have_dist,
-                                             double g_or_dist, const double q_near[DIM], const double q[DIM],
-                                             const double (*obs)[64], uint32_t ns64, Work<DIM>& work) {
-    double q_new[DIM];
+struct QSlot {
+    double q[DIM];
+    uint64_t pos_after;  // stream position after this query's draws
+};
+
+template <int DIM>
+struct PipeShared {
+    uint32_t rng_buf[16][64];
+    QSlot<DIM> qring[kRing];
+    WavePub<DIM> pub[kRing][kScanWaves];
+    uint32_t base_n[kRing][kScanWaves];  // tree size each wave's scan covered
+    uint32_t done[kRing];                // scanner waves that have published this slot
+    double newn[64][DIM];                // the last 64 committed nodes, node i at i & 63
+    uint32_t sampled;                    // queries sampled so far   (monotonic)
+    uint32_t resolved;                   // queries resolved so far  (monotonic)
+    uint32_t committed;                  // tree size                (monotonic)
+    uint32_t stop_flag;                  // resolver -> scanners: leave
+};
+
+// LDS executes one wave's instructions in order and is a single pipeline per CU, so "write data,
+// then write flag" / "read flag, then read data" need compiler ordering only.
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) {
+    uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_post(uint32_t* p, uint32_t v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_bump(uint32_t* p) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umin_step(uint32_t v) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_umin_step<0xB1, 0xf>(v);
+    v = dpp_umin_step<0x4E, 0xf>(v);
+    v = dpp_umin_step<0x141, 0xf>(v);
+    v = dpp_umin_step<0x140, 0xf>(v);
+    v = dpp_umin_step<0x142, 0xa>(v);
+    v = dpp_umin_step<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// steer (rrt.rs:199-208) + check_motion (rrt.rs:90-116) in the resolver wave, one obstacle per
+// lane (registers).  A conservative midpoint filter settles most motions with one distance per
+// sphere: every interpolated state lies within max_distance/2 of the segment midpoint, so
+// d2(centre, mid) > (r + max_distance/2 + margin)^2 proves the sphere cannot be hit.  Only if a
+// sphere fails the filter are the interpolated states tested, exactly as the reference does; the
+// verdict is identical either way (the filter only skips provably valid work).
+template <int DIM>
+__device__ __forceinline__ bool steer_and_check(const DevParams& p, uint32_t lane, bool have_dist, double g_or_dist,
+                                                const double q_near[DIM], const double q[DIM], const double oc[DIM],
+                                                double othr, double ofilt, uint32_t ns64, double q_new[DIM]) {
     const bool far = have_dist ? (g_or_dist > p.max_distance) : (g_or_dist > p.t_steer);
     if (far) {
         const double md = have_dist ? g_or_dist : sqrt(g_or_dist);
@@ -142,136 +190,114 @@ __device__ __forceinline__ void resolve_tail(const DevParams& p, uint32_t lane, 
         for (int k = 0; k < DIM; ++k) q_new[k] = q[k];
     }
     const uint32_t nobs = p.n_spheres + p.n_boxes;
-    bool ok = true;
-    if (nobs > 0) {
-        double c[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) c[k] = obs[k][lane];
-        const double thr = obs[DIM][lane], filt = obs[DIM + 1][lane];
-        double mid[DIM];
-        lerp<DIM>(q_near, q_new, 0.5, mid, DIM);
-        const bool maybe = !(dist2<DIM>(c, mid, DIM) > filt);
-        const bool extras = nobs > ns64;  // spheres beyond the first 64 and every box: always stepped
-        if (__ballot(maybe) != 0 || extras) {
-            const double dist = sqrt(dist2<DIM>(q_near, q_new, DIM));
-            const uint32_t nsteps = num_steps_u32(dist, p.res);
-            bool bad = false;
-            if (nsteps <= 1) {
-                bad = !(dist2<DIM>(c, q_new, DIM) > thr);
-                for (uint32_t j = ns64 + lane; j < nobs; j += 64) bad = bad || obstacle_hit<DIM>(p, DIM, q_new, j);
-            } else {
-                const double dn = (double)nsteps;
-                const double tl = (double)(lane + 1) / dn;  // lane s-1 holds s / nsteps (one division, all lanes)
-                for (uint32_t s = 1; s <= nsteps; ++s) {
-                    const double t = (s <= 64) ? readlane_f64(tl, (int)(s - 1)) : ((double)s / dn);
-                    double x[DIM];
-                    lerp<DIM>(q_near, q_new, t, x, DIM);
-                    bad = bad || !(dist2<DIM>(c, x, DIM) > thr);
-                    for (uint32_t j = ns64 + lane; j < nobs; j += 64) bad = bad || obstacle_hit<DIM>(p, DIM, x, j);
-                    if (__ballot(bad) != 0) break;  // the reference also stops at the first invalid state
-                }
-            }
-            ok = __ballot(bad) == 0;
+    if (nobs == 0) return true;
+    double mid[DIM];
+    lerp<DIM>(q_near, q_new, 0.5, mid, DIM);
+    const bool maybe = !(dist2<DIM>(oc, mid, DIM) > ofilt);
+    const bool extras = nobs > ns64;  // spheres beyond the first 64 and every box: always stepped
+    if (__ballot(maybe) == 0 && !extras) return true;
+    const double dist = sqrt(dist2<DIM>(q_near, q_new, DIM));
+    const uint32_t nsteps = num_steps_u32(dist, p.res);
+    bool bad = false;
+    if (nsteps <= 1) {
+        bad = !(dist2<DIM>(oc, q_new, DIM) > othr);
+        for (uint32_t j = ns64 + lane; j < nobs; j += 64) bad = bad || obstacle_hit<DIM>(p, DIM, q_new, j);
+    } else {
+        const double dn = (double)nsteps;
+        const double tl = (double)(lane + 1) / dn;  // lane s-1 holds s / nsteps (one division for all steps)
+        for (uint32_t s = 1; s <= nsteps; ++s) {
+            const double t = (s <= 64) ? readlane_f64(tl, (int)(s - 1)) : ((double)s / dn);
+            double x[DIM];
+            lerp<DIM>(q_near, q_new, t, x, DIM);
+            bad = bad || !(dist2<DIM>(oc, x, DIM) > othr);
+            for (uint32_t j = ns64 + lane; j < nobs; j += 64) bad = bad || obstacle_hit<DIM>(p, DIM, x, j);
+            if (__ballot(bad) != 0) break;  // the reference also stops at the first invalid state
         }
     }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) work.q_new[k] = q_new[k];
-        work.nearest = nearest;
-        work.ok = ok ? 1u : 0u;
-        work.mode = 0;
-    }
+    return __ballot(bad) == 0;
 }
 
 template <int DIM, int S, bool STAMP>
-__global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) {
+__global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p) {
     constexpr int D = DIM;
-    constexpr uint32_t kResolver = 0, kSampler = kResWaves - 1;
     const uint32_t prob = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = uni(tid >> 6), lane = tid & 63;
 
-    __shared__ uint32_t rng_buf[16][64];
-    __shared__ WavePub<DIM> pub[kResWaves];
-    __shared__ WaveExact<DIM> epub[kResWaves];
-    __shared__ QRec<DIM> qrec[2];
-    __shared__ Work<DIM> work;
-    __shared__ double obs[DIM + 2][64];  // first 64 spheres: centre, validity threshold, filter threshold
+    __shared__ PipeShared<DIM> sh;
 
-    ProblemState st = p.state[prob];
-    if (p.stop_at_goal && st.goal_node >= 0) return;
+    const ProblemState st0 = p.state[prob];
+    if (p.stop_at_goal && st0.goal_node >= 0) return;
 
     const size_t cap = p.cap;
     double* tree = p.tree + (size_t)prob * DIM * cap;
     int32_t* parent = p.parent + (size_t)prob * cap;
-    double goal_c[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
-    const double goal_thr = p.goal_thr[prob];
-    const uint32_t ns64 = p.n_spheres < 64 ? p.n_spheres : 64;
+    uint8_t* skip = p.skip + (size_t)prob * cap;
+    const uint32_t budget = (uint32_t)p.budget;  // the host keeps a launch's budget below 2^31
 
-    uint32_t n = st.n_nodes;
-
-    // the tree, in registers: node (tid + 1024*s) in tr[.][s]; empty slots hold +inf (d2 = inf never wins)
-    double tr[DIM][S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        uint32_t i = tid + kResThreads * s;
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) tr[k][s] = (i < n) ? tree[(size_t)k * cap + i] : __builtin_inf();
+    if (tid < kRing) sh.done[tid] = 0;
+    if (tid == 0) {
+        sh.sampled = 0;
+        sh.resolved = 0;
+        sh.committed = st0.n_nodes;
+        sh.stop_flag = 0;
     }
-    if (tid < 64) {  // unused lanes hold a sphere that can never be hit
-#pragma unroll
-        for (int k = 0; k < D; ++k) obs[k][tid] = tid < ns64 ? p.sph_c[(size_t)k * p.n_spheres + tid] : 0.0;
-        obs[D][tid] = tid < ns64 ? p.sph_thr[tid] : -1.0;
-        obs[D + 1][tid] = tid < ns64 ? p.sph_filt[tid] : -1.0;
-    }
+    __syncthreads();  // the only workgroup barrier of the launch
 
-    // the sampler wave owns the RNG window and works one query ahead (rrt.rs:177-184)
-    RngWindow rng;
-    rng.init(rng_buf, p.seed, p.first_problem_id + prob, st.draws);
-    uint64_t draws_done = st.draws;
-    if (wave == kSampler && p.budget > 0) {
-        double q0[D];
-        sample_state<D, false>(rng, p, DIM, goal_c, q0);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < D; ++k) qrec[0].q[k] = q0[k];
-            qrec[0].pos_after = rng.pos;
-        }
-    }
-    __syncthreads();
-
-    uint64_t t_scan = 0, t_b1 = 0, t_res = 0, t_b2 = 0, t_ins = 0, t_mark = 0, wave_arr = 0, t_rel = 0;
-#define OXHIP_STAMP(acc)                                   \
-    if (STAMP) {                                           \
-        uint64_t now_ = (uint64_t)clock64();               \
-        acc += now_ - t_mark;                              \
-        t_mark = now_;                                     \
-    }
-    if (STAMP) { t_mark = (uint64_t)clock64(); t_rel = t_mark; }
-
-    uint32_t par = 0;
-    int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
-    for (uint64_t it = 0; it < p.budget; ++it, par ^= 1) {
-        if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
-
-        // ---- phase A (all waves): scan the register tree for this iteration's query (rrt.rs:187-196)
-        double q[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) q[k] = qrec[par].q[k];
-        const uint32_t nslots = uni((n + kResThreads - 1) / kResThreads);
-        Scan sc{__builtin_inf(), 0u, 0xFFFFFFFFu};
+    if (wave < kScanWaves) {
+        // ================================================================= scanner waves
+        uint32_t n_local = st0.n_nodes;
+        double tr[DIM][S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            if ((uint32_t)s < nslots) {
-                double c[D];
+            uint32_t i = tid + kScanThreads * s;
+            const bool live = i < n_local && skip[i] == 0;  // duplicates of a lower-index node never win: hold +inf
 #pragma unroll
-                for (int k = 0; k < D; ++k) c[k] = tr[k][s];
-                scan_push(sc, dist2<D>(c, q, DIM), (uint32_t)s);
-            }
+            for (int k = 0; k < DIM; ++k) tr[k][s] = live ? tree[(size_t)k * cap + i] : __builtin_inf();
         }
-        {
+        uint64_t t_wait = 0, t_work = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
+        uint32_t seen_sampled = 0;
+        for (uint32_t j = 0; j < budget; ++j) {
+            // wait until query j has been sampled (implies its ring slot was consumed kRing queries ago)
+            for (uint32_t spins = 0; seen_sampled <= j; ++spins) {
+                if (lds_peek(&sh.stop_flag) != 0 || spins > kMaxSpins) break;  // every spin is bounded
+                seen_sampled = uni(lds_peek(&sh.sampled));
+                if (seen_sampled <= j) __builtin_amdgcn_s_sleep(2);
+            }
+            if (seen_sampled <= j) break;  // stop requested
+            if (STAMP) { uint64_t now = (uint64_t)clock64(); t_wait += now - t_mark; t_mark = now; }
+            const uint32_t slot = j & (kRing - 1);
+            // absorb the nodes committed since this wave's last snapshot (the owner lane takes each)
+            const uint32_t nc = uni(lds_peek(&sh.committed));
+            for (uint32_t i = n_local; i < nc; ++i) {
+                const uint32_t sl = i / kScanThreads;
+                const bool mine = tid == (i % kScanThreads);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (sl == (uint32_t)s) {
+                        if (mine) {
+#pragma unroll
+                            for (int k = 0; k < D; ++k) tr[k][s] = sh.newn[i & 63][k];
+                        }
+                    }
+                }
+            }
+            n_local = nc;
+            double q[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) q[k] = unid(sh.qring[slot].q[k]);
+            // nearest neighbour over this wave's nodes (rrt.rs:187-196), d2 compare
+            const uint32_t nslots = (nc + kScanThreads - 1) / kScanThreads;
+            Scan sc{__builtin_inf(), 0u, 0xFFFFFFFFu};
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if ((uint32_t)s < nslots) {
+                    double c[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) c[k] = tr[k][s];
+                    scan_push(sc, dist2<D>(c, q, DIM), (uint32_t)s);
+                }
+            }
             const double wmin = wave_min_f64(sc.b1);
             const uint64_t eqm = __ballot(sc.b1 == wmin);
             const int wl = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
@@ -279,160 +305,201 @@ __global__ __launch_bounds__(kResThreads) void rrt_resident_kernel(DevParams p) 
             const uint32_t hb = hi32(wmin) + 1;
             const bool amb_l = ((int)lane != wl && hi32(sc.b1) <= hb) || (sc.h2 <= hb);
             const uint32_t wamb = __ballot(amb_l) != 0 ? 1u : 0u;
-            store_slot<DIM, S>(tr, wslot, (int)lane == wl, pub[wave].c);
+            WavePub<DIM>& out = sh.pub[slot][wave];
+            store_slot<DIM, S>(tr, wslot, (int)lane == wl, out.c);
             if (lane == 0) {
-                pub[wave].b1 = wmin;
-                pub[wave].i1 = (wave << 6) + (uint32_t)wl + (wslot << 10);
-                pub[wave].amb = wamb;
+                out.b1 = wmin;
+                out.i1 = (wave << 6) + (uint32_t)wl + wslot * kScanThreads;
+                out.amb = wamb;
+                sh.base_n[slot][wave] = nc;
+                lds_bump(&sh.done[slot]);
             }
+            if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
         }
-        if (STAMP) wave_arr += (uint64_t)clock64() - t_rel;
-        OXHIP_STAMP(t_scan)
-        __syncthreads();
-        OXHIP_STAMP(t_b1)
+        if (STAMP && p.dbg && prob == 0 && lane == 0) {
+            p.dbg[16 + wave] = t_wait;
+            p.dbg[24 + wave] = t_work;
+        }
+        return;
+    }
 
-        // ---- phase B: wave 0 resolves (nearest over 16 candidates, steer, motion check);
-        //      wave 15 samples the next query meanwhile; the others wait
-        if (wave == kResolver) {
-            const bool in = lane < kResWaves;
-            const double pb = in ? pub[in ? lane : 0].b1 : __builtin_inf();
-            const uint32_t pamb = in ? pub[in ? lane : 0].amb : 0u;
-            const double g = wave_min_f64(pb);
-            const uint64_t m2 = __ballot(in && pb == g);
-            const int ww = m2 ? (__ffsll((unsigned long long)m2) - 1) : 0;
-            const uint32_t hb = hi32(g) + 1;
-            const bool amb = (__popcll(m2) > 1) || (__ballot(in && (pamb != 0 || ((int)lane != ww && hi32(pb) <= hb))) != 0);
-            if (!amb) {
-                double q_near[D];
+    // ===================================================================== resolver wave
+    __builtin_amdgcn_s_setprio(3);  // the youngest wave of its SIMD would otherwise queue behind two scanners
+    ProblemState st = st0;
+    double goal_c[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) q_near[k] = pub[ww].c[k];
-                resolve_tail<DIM>(p, lane, pub[ww].i1, false, g, q_near, q, obs, ns64, work);
-            } else if (lane == 0) {
-                work.mode = 1;
-            }
-        } else if (wave == kSampler) {
-            if (it + 1 < p.budget) {
-                double qn[D];
-                sample_state<D, false>(rng, p, DIM, goal_c, qn);
-                if (lane == 0) {
+    for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
+    const double goal_thr = p.goal_thr[prob];
+    const uint32_t ns64 = p.n_spheres < 64 ? p.n_spheres : 64;
+    // this lane's obstacle (unused lanes hold a sphere that can never be hit)
+    double oc[D];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) qrec[par ^ 1].q[k] = qn[k];
-                    qrec[par ^ 1].pos_after = rng.pos;
-                }
+    for (int k = 0; k < D; ++k) oc[k] = lane < ns64 ? p.sph_c[(size_t)k * p.n_spheres + lane] : 0.0;
+    const double othr = lane < ns64 ? p.sph_thr[lane] : -1.0;
+    const double ofilt = lane < ns64 ? p.sph_filt[lane] : -1.0;
+    // this lane's recent node: the last committed node i with (i & 63) == lane
+    double pn[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) pn[k] = 0.0;
+    uint32_t pidx = kNoNode;
+
+    RngWindow rng;
+    rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
+    uint64_t draws_done = st.draws;
+    uint32_t n = st.n_nodes;
+    uint32_t js = 0;
+    int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
+    uint64_t t_wait = 0, t_work = 0, t_samp = 0, t_comb = 0, n_amb = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
+
+    for (uint32_t jr = 0; jr < budget; ++jr) {
+        if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
+        // sample ahead (rrt.rs:177-184); a query may only reuse a ring slot after its previous tenant was resolved
+        while (js < budget && js < jr + kRing) {
+            double qn[D];
+            sample_state<D, false>(rng, p, DIM, goal_c, qn);
+            QSlot<DIM>& qs = sh.qring[js & (kRing - 1)];
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) qs.q[k] = qn[k];
+                qs.pos_after = rng.pos;
             }
+            ++js;
+            if (lane == 0) lds_post(&sh.sampled, js);
         }
-        OXHIP_STAMP(t_res)
-        __syncthreads();
-        if (uni(work.mode) != 0) {
-            // rare: two d2 with (nearly) equal high dwords -> post-sqrt compare with lowest-index ties,
-            // literally as the reference does
-            Exact e{__builtin_inf(), 0xFFFFFFFFu};
+        if (STAMP) { uint64_t now = (uint64_t)clock64(); t_samp += now - t_mark; t_mark = now; }
+        const uint32_t slot = jr & (kRing - 1);
+        uint32_t spins = 0;
+        while (uni(lds_peek(&sh.done[slot])) < (uint32_t)kScanWaves && spins <= kMaxSpins) {
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
+        }
+        if (spins > kMaxSpins) { stop = 4; break; }  // OXHIP_STOP_INTERNAL: a scanner never published (bug guard)
+        if (STAMP) { uint64_t now = (uint64_t)clock64(); t_wait += now - t_mark; t_mark = now; }
+
+        double q[D];
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if ((uint32_t)s < nslots) {
-                    double c[D];
+        for (int k = 0; k < D; ++k) q[k] = unid(sh.qring[slot].q[k]);
+        // candidates: one per scanner wave (lanes 0..7) + the recent nodes the scans did not cover (all lanes)
+        const bool inS = lane < (uint32_t)kScanWaves;
+        const WavePub<DIM>& mine = sh.pub[slot][inS ? lane : 0];
+        const double pb = inS ? mine.b1 : __builtin_inf();
+        const uint32_t pamb = inS ? mine.amb : 0u;
+        const uint32_t pidxS = inS ? mine.i1 : kNoNode;
+        const uint32_t base_min = wave_min_u32(inS ? sh.base_n[slot][lane] : kNoNode);
+        const bool pv = pidx != kNoNode && pidx >= base_min;
+        const double d2p = pv ? dist2<D>(pn, q, DIM) : __builtin_inf();
+        const double g1 = wave_min_f64(pb), g2 = wave_min_f64(d2p);
+        const double g = g2 < g1 ? g2 : g1;
+        const uint32_t hb = hi32(g) + 1;
+        const bool nearS = inS && hi32(pb) <= hb;
+        const bool nearP = pv && hi32(d2p) <= hb;
+        const uint64_t mS = __ballot(nearS), mP = __ballot(nearP);
+        const bool from_scan = mS != 0;
+        const int wl = from_scan ? (__ffsll((unsigned long long)mS) - 1) : (mP ? (__ffsll((unsigned long long)mP) - 1) : 0);
+        uint32_t nearest = from_scan ? (uint32_t)__builtin_amdgcn_readlane((int)pidxS, wl)
+                                     : (uint32_t)__builtin_amdgcn_readlane((int)pidx, wl);
+        // unambiguous iff every near candidate is that one node and no near wave saw a second near node
+        const bool amb = __ballot((nearS && (pidxS != nearest || pamb != 0)) || (nearP && pidx != nearest)) != 0;
+
+        if (STAMP) { uint64_t now = (uint64_t)clock64(); t_comb += now - t_mark; t_mark = now; if (amb) ++n_amb; }
+        double q_near[D], q_new[D];
+        bool ok;
+        bool dup;  // q coincides with its nearest node: an accepted q_new is then a coordinate duplicate of it
+        if (!amb) {
+            dup = g == 0.0;
 #pragma unroll
-                    for (int k = 0; k < D; ++k) c[k] = tr[k][s];
-                    double d = sqrt(dist2<D>(c, q, DIM));
-                    if (d < e.dist) { e.dist = d; e.idx = tid + kResThreads * s; }
-                }
+            for (int k = 0; k < D; ++k) q_near[k] = from_scan ? unid(sh.pub[slot][wl].c[k]) : readlane_f64(pn[k], wl);
+            ok = steer_and_check<DIM>(p, lane, false, g, q_near, q, oc, othr, ofilt, ns64, q_new);
+        } else {
+            // rare (~1e-6 of queries, or exact duplicates): the reference's own loop -- post-sqrt compare with
+            // lowest-index ties -- over the persistent copy of the tree in global memory
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            Exact e{__builtin_inf(), kNoNode};
+            for (uint32_t i = lane; i < n; i += 64) {
+                double c[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+                    c[k] = __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double d = sqrt(dist2<D>(c, q, DIM));
+                if (d < e.dist) { e.dist = d; e.idx = i; }
             }
             e = exact_wave_reduce(e);
-            const uint32_t eidx = uni(e.idx);
-            store_slot<DIM, S>(tr, eidx >> 10, lane == (eidx & 63u), epub[wave].c);
-            if (lane == 0) {
-                epub[wave].dist = unid(e.dist);
-                epub[wave].idx = eidx;
-            }
-            __syncthreads();
-            if (wave == kResolver) {
-                int bw = 0;
-                Exact be{epub[0].dist, epub[0].idx};
-                for (int w = 1; w < kResWaves; ++w) {
-                    Exact o{epub[w].dist, epub[w].idx};
-                    if ((o.dist < be.dist) || (o.dist == be.dist && o.idx < be.idx)) { be = o; bw = w; }
-                }
-                bw = (int)uni((uint32_t)bw);
-                double q_near[D];
+            nearest = uni(e.idx);
 #pragma unroll
-                for (int k = 0; k < D; ++k) q_near[k] = epub[bw].c[k];
-                resolve_tail<DIM>(p, lane, uni(be.idx), true, unid(be.dist), q_near, q, obs, ns64, work);
-            }
-            __syncthreads();
+            for (int k = 0; k < D; ++k)
+                q_near[k] = unid(__hip_atomic_load(&tree[(size_t)k * cap + nearest], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            ok = steer_and_check<DIM>(p, lane, true, unid(e.dist), q_near, q, oc, othr, ofilt, ns64, q_new);
+            dup = unid(e.dist) == 0.0;
         }
-        if (STAMP) t_rel = (uint64_t)clock64();
-        OXHIP_STAMP(t_b2)
 
-        // ---- phase D (all waves): verdict, insert into the owner's registers, goal test
-        const bool ok = uni(work.ok) != 0;
-        const uint32_t nearest = uni(work.nearest);
-        double q_new[D];
+        // bookkeeping (wave-uniform, on the scalar unit where the compiler can)
+        uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
 #pragma unroll
-        for (int k = 0; k < D; ++k) q_new[k] = work.q_new[k];
-        draws_done = qrec[par].pos_after;
-        if (wave == 0) {  // bookkeeping is only ever read back from thread 0
-            uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
-#pragma unroll
-            for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(q_new[k])));
-            st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
-            st.iterations++;
-            if (ok) st.accepted++;
-        }
+        for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(q_new[k])));
+        st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
+        st.iterations++;
+        draws_done = sh.qring[slot].pos_after;
         bool hit = false;
-        if (ok && !p.freeze) {
-            // 6. insert (rrt.rs:213-217): the owner thread takes the node into its registers
-            const uint32_t slot = n >> 10;
-            const bool owner = tid == (n & (kResThreads - 1));
+        if (ok) {
+            st.accepted++;
+            if (!p.freeze) {
+                // 6. insert (rrt.rs:213-217): recent-node lane, LDS hand-off to the owning scanner lane, HBM copy
+                const uint32_t i = n;
+                // A node at distance 0 from its nearest node repeats that node's coordinates, and the strict '<'
+                // of rrt.rs:192 can never prefer it over the lower index: the scanners keep +inf for it.
+                if (lane == (i & 63)) {
+                    pidx = i;
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if (slot == (uint32_t)s) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) tr[k][s] = owner ? q_new[k] : tr[k][s];
+                    for (int k = 0; k < D; ++k) {
+                        const double live = dup ? __builtin_inf() : q_new[k];
+                        pn[k] = live;
+                        sh.newn[i & 63][k] = live;
+                        tree[(size_t)k * cap + i] = q_new[k];
+                    }
+                    parent[i] = (int32_t)nearest;
+                    skip[i] = dup ? 1 : 0;
+                }
+                ++n;
+                if (lane == 0) lds_post(&sh.committed, n);
+                // 7. goal test (rrt.rs:220-223)
+                if (dist2<D>(q_new, goal_c, DIM) <= goal_thr) {
+                    if (st.goal_node < 0) st.goal_node = (int32_t)i;
+                    hit = true;
                 }
             }
-            if (owner) {
-#pragma unroll
-                for (int k = 0; k < D; ++k) tree[(size_t)k * cap + n] = q_new[k];
-                parent[n] = (int32_t)nearest;
-            }
-            ++n;
-            // 7. goal test (rrt.rs:220-223)
-            if (dist2<D>(q_new, goal_c, DIM) <= goal_thr) {
-                if (st.goal_node < 0) st.goal_node = (int32_t)(n - 1);
-                hit = true;
-            }
         }
-        OXHIP_STAMP(t_ins)
+        if (lane == 0) {
+            lds_post(&sh.done[slot], 0);          // free the slot ...
+            lds_post(&sh.resolved, jr + 1);       // ... before the sampler may hand it out again
+        }
+        if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
         if (hit && p.stop_at_goal) { stop = 0; break; }
     }
-#undef OXHIP_STAMP
-
-    if (STAMP && p.dbg && prob == 0 && lane == 0) p.dbg[16 + wave] = wave_arr;
-    if (tid == 0) {
+    if (lane == 0) {
+        lds_post(&sh.stop_flag, 1);
         st.n_nodes = n;
         st.draws = draws_done;
         st.stop_reason = stop;
         p.state[prob] = st;
         if (STAMP && p.dbg && prob == 0) {
-            p.dbg[0] = t_scan; p.dbg[1] = t_b1; p.dbg[2] = t_res; p.dbg[3] = t_b2; p.dbg[4] = 0;
-            p.dbg[5] = 0; p.dbg[6] = t_ins; p.dbg[7] = st.iterations;
+            p.dbg[0] = t_samp; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_comb; p.dbg[4] = n_amb; p.dbg[7] = st.iterations;
         }
     }
 }
 
-// instantiations: (dim, slots) -> capacity 1024 * slots nodes
+// instantiations: (dim, slots) -> capacity 512 * slots nodes
 static int pick_slots(uint32_t cap) {
-    const uint32_t need = (cap + kResThreads - 1) / kResThreads;
-    if (need <= 2) return 2;
+    const uint32_t need = (cap + kScanThreads - 1) / kScanThreads;
     if (need <= 4) return 4;
-    if (need <= 10) return 10;
+    if (need <= 20) return 20;
     return 0;
 }
 
 bool resident_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && pick_slots(cap) != 0; }
 
 void launch_rrt_resident(const DevParams& p, hipStream_t stream) {
-    dim3 grid(p.n_problems), block(kResThreads);
+    dim3 grid(p.n_problems), block(kPipeThreads);
     const int s = pick_slots(p.cap);
 #define OXHIP_LAUNCH(DIM_, S_)                                                                              \
     do {                                                                                                    \
@@ -440,9 +507,9 @@ void launch_rrt_resident(const DevParams& p, hipStream_t stream) {
         else hipLaunchKernelGGL((rrt_resident_kernel<DIM_, S_, false>), grid, block, 0, stream, p);         \
     } while (0)
     if (p.dim == 3) {
-        if (s == 2) OXHIP_LAUNCH(3, 2); else if (s == 4) OXHIP_LAUNCH(3, 4); else OXHIP_LAUNCH(3, 10);
+        if (s == 4) OXHIP_LAUNCH(3, 4); else OXHIP_LAUNCH(3, 20);
     } else {
-        if (s == 2) OXHIP_LAUNCH(2, 2); else if (s == 4) OXHIP_LAUNCH(2, 4); else OXHIP_LAUNCH(2, 10);
+        if (s == 4) OXHIP_LAUNCH(2, 4); else OXHIP_LAUNCH(2, 20);
     }
 #undef OXHIP_LAUNCH
 }

@@ -215,8 +215,10 @@ def test_rrt_matches_golden_fixtures(golden, key, kernel):
               goal_centre=params["goal_c"], goal_radius=params["goal_r"],
               spheres=params_spheres(params) if params["spheres"] else None,
               boxes=params_boxes(params) if params["boxes"] else None)
+    # the fixtures finish far below 10,000 nodes, so the resident kernel's capacity gives the same trees
+    max_nodes = params["max_nodes"] if kernel == capi.KERNEL_STREAM else 10000
     for run in golden[key]["runs"]:
-        gpu = _gpu_for(sc, 1, params["max_nodes"], True, run["seed"], run["pid"], kernel)
+        gpu = _gpu_for(sc, 1, max_nodes, True, run["seed"], run["pid"], kernel)
         st = gpu.solve(params["max_iterations"])
         assert st[0] == capi.OK
         c = gpu.counts()

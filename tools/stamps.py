@@ -15,11 +15,8 @@ gpu.solve(10 ** 7)
 gpu.enable_stamps(True)
 gpu.solve(iters, freeze=True)
 s = gpu.stamps()
-names = ["scan+publish", "barrier1", "resolve|sample", "barrier2", "-", "-", "verdict+insert"]
-tot = float(sum(int(v) for v in s[:7]))
-print("steady@10k, %d iterations, kernel %.3f ms" % (iters, gpu.last_timing()["kernel_ms"]))
-for nme, v in zip(names, s[:7]):
-    print("  %-16s %12d cyc  %6.1f cyc/iter  %5.1f %%" % (nme, int(v), int(v) / iters, 100.0 * int(v) / tot))
-print("  total %.1f cyc/iter" % (tot / iters))
-print("  per-wave arrival at barrier 1 after barrier-3 release (cyc/iter):")
-print("   ", " ".join("%5.0f" % (int(v) / iters) for v in s[16:32]))
+print("steady@10k, %d iterations, kernel %.3f ms (diagnostic build)" % (iters, gpu.last_timing()["kernel_ms"]))
+print("resolver wave: sample %.0f  wait-for-scanners %.0f  resolve+commit %.0f  cyc/iter" % tuple(int(v) / iters for v in s[:3]))
+print("   of which combine %.0f cyc/iter; exact-path events %d of %d" % (int(s[3]) / iters, int(s[4]), iters))
+print("scanner waves: wait   ", " ".join("%6.0f" % (int(v) / iters) for v in s[16:24]))
+print("               scan   ", " ".join("%6.0f" % (int(v) / iters) for v in s[24:32]))
