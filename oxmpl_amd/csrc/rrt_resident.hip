@@ -116,6 +116,8 @@ constexpr int kScanWaves = 8;
 constexpr int kScanThreads = kScanWaves * 64;        // 512
 constexpr int kPipeThreads = kScanThreads + 64;      // + the resolver wave
 constexpr int kRing = 16;                            // queries in flight (power of two)
+constexpr int kBatch = 4;                            // queries one scanner pass covers
+constexpr int kGroup = 4;                            // slots per uniform branch of the scan
 constexpr uint32_t kNoNode = 0xFFFFFFFFu;
 constexpr uint32_t kMaxSpins = 1u << 22;             // ~0.5 s of polling: turns a protocol bug into an error, not a hang
 
@@ -217,6 +219,77 @@ __device__ __forceinline__ bool steer_and_check(const DevParams& p, uint32_t lan
     return __ballot(bad) == 0;
 }
 
+// Lane-parallel sampling of m <= 64 consecutive queries (rrt.rs:177-184 + rvss.rs:233-249): lane l
+// produces query js + l.  A query's position in the ChaCha stream depends on how many words the
+// earlier queries drew (1 for a goal sample, 1 + DIM otherwise, more after a rejected draw), so
+// the lanes start from the no-goal guess and iterate "draw -> exclusive prefix sum of the word
+// counts" to its fix-point (one extra round per goal-biased query in the batch, on average).
+// Returns false (nothing written) if a lane would read past the LDS word window; the caller
+// then samples sequentially.
+template <int DIM>
+__device__ __forceinline__ bool sample_batch(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m,
+                                             uint32_t lane, QSlot<DIM>* qring, uint32_t js) {
+    const uint64_t win_lo = rng.base_blk * 8, win_hi = win_lo + 512;
+    const uint64_t pos0 = rng.pos;
+    if (pos0 < win_lo || pos0 >= win_hi) return false;
+    const bool always_goal = p.p_int == ~0ull;
+    const bool act = lane < m;
+    uint32_t off = always_goal ? 0u : lane * (1u + (uint32_t)DIM);  // guess: nobody before me sampled the goal
+    double q[DIM];
+    uint32_t cnt = 0;
+    bool overflow = false;
+    for (uint32_t round = 0; round <= m; ++round) {
+        uint32_t at = off;
+        auto word = [&](uint32_t rel) -> uint64_t {
+            const uint64_t a = pos0 + rel;
+            if (a >= win_hi) { overflow = true; return 0; }
+            const uint32_t bl = (uint32_t)((a >> 3) - rng.base_blk), w = (uint32_t)(a & 7) * 2;
+            return ((uint64_t)rng.buf[w + 1][bl] << 32) | rng.buf[w][bl];
+        };
+        bool goal = always_goal;
+        if (!always_goal) goal = word(at++) < p.p_int;
+        if (goal) {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) q[k] = goal_c[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                double res;
+                for (;;) {
+                    const uint64_t bits = (word(at++) >> 12) | 0x3FF0000000000000ull;
+                    const double v01 = __longlong_as_double((long long)bits) - 1.0;
+                    res = v01 * p.scale[k];
+                    res = res + p.lo[k];
+                    if (res < p.hi[k] || overflow) break;
+                }
+                q[k] = res;
+            }
+        }
+        cnt = act ? (at - off) : 0u;
+        // exclusive prefix sum of cnt over the lanes
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+            if ((int)lane >= d) incl += o;
+        }
+        const uint32_t true_off = incl - cnt;
+        const bool same = !act || true_off == off;
+        off = true_off;
+        if (__ballot(!same) == 0) break;
+    }
+    if (__ballot(act && overflow) != 0) return false;
+    if (act) {
+        QSlot<DIM>& qs = qring[(js + lane) & (kRing - 1)];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) qs.q[k] = q[k];
+        qs.pos_after = pos0 + off + cnt;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), (int)(m - 1));
+    rng.pos = pos0 + total;
+    return true;
+}
+
 template <int DIM, int S, bool STAMP>
 __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p) {
     constexpr int D = DIM;
@@ -257,16 +330,19 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         }
         uint64_t t_wait = 0, t_work = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
         uint32_t seen_sampled = 0;
-        for (uint32_t j = 0; j < budget; ++j) {
-            // wait until query j has been sampled (implies its ring slot was consumed kRing queries ago)
-            for (uint32_t spins = 0; seen_sampled <= j; ++spins) {
+        for (uint32_t j = 0; j < budget; j += kBatch) {
+            // one pass scans kBatch queries (the tail pass may hold one): fixed costs are shared, the two
+            // reductions are independent dependency chains
+            const uint32_t nb = (budget - j < (uint32_t)kBatch) ? (budget - j) : (uint32_t)kBatch;
+            const uint32_t need = j + nb;
+            // wait until the pass's queries are sampled (implies their ring slots were consumed kRing queries ago)
+            for (uint32_t spins = 0; seen_sampled < need; ++spins) {
                 if (lds_peek(&sh.stop_flag) != 0 || spins > kMaxSpins) break;  // every spin is bounded
                 seen_sampled = uni(lds_peek(&sh.sampled));
-                if (seen_sampled <= j) __builtin_amdgcn_s_sleep(2);
+                if (seen_sampled < need) __builtin_amdgcn_s_sleep(2);
             }
-            if (seen_sampled <= j) break;  // stop requested
+            if (seen_sampled < need) break;  // stop requested
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_wait += now - t_mark; t_mark = now; }
-            const uint32_t slot = j & (kRing - 1);
             // absorb the nodes committed since this wave's last snapshot (the owner lane takes each)
             const uint32_t nc = uni(lds_peek(&sh.committed));
             for (uint32_t i = n_local; i < nc; ++i) {
@@ -283,36 +359,55 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                 }
             }
             n_local = nc;
-            double q[D];
+            double q[kBatch][D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) q[k] = unid(sh.qring[slot].q[k]);
+            for (int b = 0; b < kBatch; ++b) {
+                const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kRing - 1);
+#pragma unroll
+                for (int k = 0; k < D; ++k) q[b][k] = unid(sh.qring[slot].q[k]);
+            }
             // nearest neighbour over this wave's nodes (rrt.rs:187-196), d2 compare
             const uint32_t nslots = (nc + kScanThreads - 1) / kScanThreads;
-            Scan sc{__builtin_inf(), 0u, 0xFFFFFFFFu};
+            Scan sc[kBatch];
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                if ((uint32_t)s < nslots) {
-                    double c[D];
+            for (int b = 0; b < kBatch; ++b) sc[b] = Scan{__builtin_inf(), 0u, 0xFFFFFFFFu};
+            // slots are visited in groups of kGroup under ONE uniform branch: inside a group the code is
+            // straight-line, so the scheduler interleaves kGroup x kBatch independent sub/mul/add chains
+            // (empty slots hold +inf and can never win)
 #pragma unroll
-                    for (int k = 0; k < D; ++k) c[k] = tr[k][s];
-                    scan_push(sc, dist2<D>(c, q, DIM), (uint32_t)s);
+            for (int g0 = 0; g0 < S; g0 += kGroup) {
+                if ((uint32_t)g0 < nslots) {
+#pragma unroll
+                    for (int s = g0; s < g0 + kGroup && s < S; ++s) {
+                        double c[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) c[k] = tr[k][s];
+#pragma unroll
+                        for (int b = 0; b < kBatch; ++b) scan_push(sc[b], dist2<D>(c, q[b], DIM), (uint32_t)s);
+                    }
                 }
             }
-            const double wmin = wave_min_f64(sc.b1);
-            const uint64_t eqm = __ballot(sc.b1 == wmin);
-            const int wl = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
-            const uint32_t wslot = __builtin_amdgcn_readlane(sc.slot, wl);
-            const uint32_t hb = hi32(wmin) + 1;
-            const bool amb_l = ((int)lane != wl && hi32(sc.b1) <= hb) || (sc.h2 <= hb);
-            const uint32_t wamb = __ballot(amb_l) != 0 ? 1u : 0u;
-            WavePub<DIM>& out = sh.pub[slot][wave];
-            store_slot<DIM, S>(tr, wslot, (int)lane == wl, out.c);
-            if (lane == 0) {
-                out.b1 = wmin;
-                out.i1 = (wave << 6) + (uint32_t)wl + wslot * kScanThreads;
-                out.amb = wamb;
-                sh.base_n[slot][wave] = nc;
-                lds_bump(&sh.done[slot]);
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                if ((uint32_t)b < nb) {
+                    const uint32_t slot = (j + (uint32_t)b) & (kRing - 1);
+                    const double wmin = wave_min_f64(sc[b].b1);
+                    const uint64_t eqm = __ballot(sc[b].b1 == wmin);
+                    const int wl = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
+                    const uint32_t wslot = __builtin_amdgcn_readlane(sc[b].slot, wl);
+                    const uint32_t hb = hi32(wmin) + 1;
+                    const bool amb_l = ((int)lane != wl && hi32(sc[b].b1) <= hb) || (sc[b].h2 <= hb);
+                    const uint32_t wamb = __ballot(amb_l) != 0 ? 1u : 0u;
+                    WavePub<DIM>& out = sh.pub[slot][wave];
+                    store_slot<DIM, S>(tr, wslot, (int)lane == wl, out.c);
+                    if (lane == 0) {
+                        out.b1 = wmin;
+                        out.i1 = (wave << 6) + (uint32_t)wl + wslot * kScanThreads;
+                        out.amb = wamb;
+                        sh.base_n[slot][wave] = nc;
+                        lds_bump(&sh.done[slot]);
+                    }
+                }
             }
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
         }
@@ -354,16 +449,31 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
     for (uint32_t jr = 0; jr < budget; ++jr) {
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
         // sample ahead (rrt.rs:177-184); a query may only reuse a ring slot after its previous tenant was resolved
-        while (js < budget && js < jr + kRing) {
-            double qn[D];
-            sample_state<D, false>(rng, p, DIM, goal_c, qn);
-            QSlot<DIM>& qs = sh.qring[js & (kRing - 1)];
-            if (lane == 0) {
+        if (js < budget && js - jr <= (uint32_t)(kRing / 2)) {
+            uint32_t m = jr + kRing - js;  // free ring slots
+            if (m > budget - js) m = budget - js;
+            // keep the batch's words inside the LDS window: refill (64 blocks from the current position) when short
+            const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + D) + 64;
+            if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
+                rng.base_blk = uni64(rng.pos >> 3);
+                uint32_t o[16];
+                chacha12_block(rng.seed, rng.base_blk + lane, rng.stream, o);
 #pragma unroll
-                for (int k = 0; k < D; ++k) qs.q[k] = qn[k];
-                qs.pos_after = rng.pos;
+                for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
             }
-            ++js;
+            if (!sample_batch<DIM>(rng, p, goal_c, m, lane, sh.qring, js)) {
+                for (uint32_t b = 0; b < m; ++b) {  // (never expected) a redraw ran past the window: one by one
+                    double qn[D];
+                    sample_state<D, false>(rng, p, DIM, goal_c, qn);
+                    QSlot<DIM>& qs = sh.qring[(js + b) & (kRing - 1)];
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) qs.q[k] = qn[k];
+                        qs.pos_after = rng.pos;
+                    }
+                }
+            }
+            js += m;
             if (lane == 0) lds_post(&sh.sampled, js);
         }
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_samp += now - t_mark; t_mark = now; }
@@ -388,8 +498,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         const uint32_t base_min = wave_min_u32(inS ? sh.base_n[slot][lane] : kNoNode);
         const bool pv = pidx != kNoNode && pidx >= base_min;
         const double d2p = pv ? dist2<D>(pn, q, DIM) : __builtin_inf();
-        const double g1 = wave_min_f64(pb), g2 = wave_min_f64(d2p);
-        const double g = g2 < g1 ? g2 : g1;
+        const double g = wave_min_f64(d2p < pb ? d2p : pb);  // one reduction over both candidate kinds
         const uint32_t hb = hi32(g) + 1;
         const bool nearS = inS && hi32(pb) <= hb;
         const bool nearP = pv && hi32(d2p) <= hb;
