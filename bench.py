@@ -31,6 +31,22 @@ if ROOT not in sys.path:
 N_NODES = 10000
 BYTES_PER_ITER = N_NODES * 3 * 8          # B(n) = n * d * 8
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
+# measured on this chip with tools/scan_bench.hip: the bare register scan (10,240 nodes, tie detector
+# included, no reduce / resolve) sustains 1.0 us per CU whatever the wave geometry -> 256 CUs
+VALU_SCAN_CEILING_ITS = 258.0e6
+
+
+def measured_traffic(kernel_name, iters_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC run (profiles/r1_traffic.json), valid
+    for the profiled shape only (1024 problems x 4096 iterations); None otherwise."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
+            t = json.load(f)[kernel_name]
+        if iters_per_launch * BYTES_PER_ITER == t["algorithmic_bytes_per_launch"]:
+            return t["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(sc, seed, threads, iters):
@@ -63,6 +79,7 @@ def main():
     ap.add_argument("--iters", type=int, default=4096, help="RRT iterations per problem per step")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stream-kernel measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,11 +102,12 @@ def main():
         torch.cuda.synchronize()
 
     import numpy as np
-    from oxmpl_amd import capi, scenarios
+    from oxmpl_amd import capi, scenarios, sharding
 
     sc = scenarios.config2()
     P, seed = args.problems, 42
-    gpu = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=rank * P,
+    first_id, _ = sharding.problem_range(rank, P)
+    gpu = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id,
                                device=local_rank, kernel=args.kernel)
     # untimed: grow every tree to 10,000 nodes (also the "grow" figure reported below)
     barrier()
@@ -120,19 +138,32 @@ def main():
     assert done == P * args.iters * (args.steps + args.warmup)
     iters_timed = P * args.iters * args.steps
 
-    stats = torch.tensor([dt, float(iters_timed), kernel_ms, float(launches), float(grow_iters), grow_s,
-                          grow_t["kernel_ms"]], dtype=torch.float64, device="cuda")
-    if world > 1:
-        allst = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(allst, stats)   # RCCL all-gather over xGMI: throughput report only
-        allst = torch.stack(allst).cpu().numpy()
-    else:
-        allst = stats.cpu().numpy()[None, :]
+    kname = {1: "stream", 2: "resident"}[gpu.last_timing()["kernel"]]
+    # secondary (rank 0, N=1 only): the HBM-streaming kernel on the same workload, 2 steps
+    secondary = None
+    if world == 1 and not args.no_secondary and kname != "stream":
+        g2 = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id,
+                                  device=local_rank, kernel=capi.KERNEL_STREAM)
+        g2.solve(10 ** 7)
+        g2.solve(args.iters, freeze=True)
+        ms2 = 0.0
+        for _ in range(2):
+            g2.solve(args.iters, freeze=True)
+            ms2 += g2.last_timing()["kernel_ms"]
+        assert np.array_equal(g2.counts()["checksum"], gpu.counts()["checksum"][:P]) or args.steps + args.warmup != 3
+        ach2 = P * args.iters * BYTES_PER_ITER / (ms2 / 2 * 1e-3) / 1e9
+        secondary = {"kernel": "stream", "iterations_per_s": P * args.iters / (ms2 / 2 * 1e-3), "kernel_avg_ms": ms2 / 2,
+                     "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": ach2 / HBM_PEAK_GBS, "traffic": measured_traffic("stream", P * args.iters)}}
+        g2.close()
+
+    # RCCL all-gather over xGMI (nccl backend): throughput report only, no data-path collective
+    allst = sharding.gather_stats([dt, float(iters_timed), kernel_ms, float(launches), float(grow_iters), grow_s,
+                                   grow_t["kernel_ms"]], device="cuda")
 
     if rank == 0:
-        t_max = float(allst[:, 0].max())
-        total_iters = float(allst[:, 1].sum())
-        value = total_iters / t_max
+        agg = sharding.aggregate(allst)
+        t_max, value = agg["t_max"], agg["value"]
         avg_launch_ms = float(allst[0, 2] / allst[0, 3])
         iters_per_launch = P * args.iters
         achieved = iters_per_launch * BYTES_PER_ITER / (avg_launch_ms * 1e-3) / 1e9
@@ -145,14 +176,20 @@ def main():
                                    "steady@10k (trees pre-grown to 10000 nodes, inserts suppressed)" % P,
                        "problems_per_gpu": P, "iterations_per_problem_per_step": args.iters, "tree_nodes": N_NODES,
                        "spheres": 64, "max_distance": 0.5, "goal_bias": 0.05, "parallelism": "problem-parallel x%d" % world,
-                       "kernel": {1: "stream", 2: "resident"}[gpu.last_timing()["kernel"]]},
+                       "kernel": kname},
+            # bound "hbm" = the roofline of any design that re-reads the tree per iteration (33.3 M it/s);
+            # the resident kernel keeps the tree in VGPRs, so frac > 1 and its own bound is f64 VALU issue
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel_avg_ms": avg_launch_ms, "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kname, iters_per_launch),
+                         "kernel_avg_ms": avg_launch_ms, "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER,
+                         "valu": {"bound": "f64-valu scan (tools/scan_bench.hip, measured)", "peak_iterations_per_s": VALU_SCAN_CEILING_ITS,
+                                  "frac": (iters_per_launch / (avg_launch_ms * 1e-3)) / VALU_SCAN_CEILING_ITS}},
             "grow": {"iterations": float(allst[:, 4].sum()), "wall_s": float(allst[:, 5].max()),
                      "iterations_per_s": float(allst[:, 4].sum() / allst[:, 5].max()),
                      "kernel_ms_rank0": float(allst[0, 6])},
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
             planners, base = cpu_baseline(sc, seed, threads, 6000)
