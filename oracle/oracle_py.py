@@ -62,6 +62,7 @@ def lib():
         L.orc_rrt_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
         L.orc_rrt_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
         L.orc_rrt_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.orc_rrt_set_tree.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int32), C.c_uint32]
         L.orc_rrt_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double]
         L.orc_rrt_num_nodes.argtypes = [C.c_void_p]
         L.orc_rrt_num_nodes.restype = C.c_uint32
@@ -178,6 +179,11 @@ class OracleRRT:
         s, ps = _d(start)
         g, pg = _d(goal_centre)
         return lib().orc_rrt_setup(self.h, ps, pg, goal_radius)
+
+    def set_tree(self, states, parents):
+        s, ps = _d(np.asarray(states, dtype=np.float64).reshape(-1, self.dim))
+        par = np.ascontiguousarray(parents, dtype=np.int32)
+        return lib().orc_rrt_set_tree(self.h, ps, par.ctypes.data_as(C.POINTER(C.c_int32)), s.shape[0])
 
     def solve(self, max_iterations, freeze=False, timeout_s=float("inf")):
         return lib().orc_rrt_solve(self.h, max_iterations, int(freeze), timeout_s)

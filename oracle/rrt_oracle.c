@@ -326,6 +326,14 @@ int orc_rrt_setup(orc_rrt* r, const double* start, const double* goal_centre, do
     return ORC_SOLVED;
 }
 
+int orc_rrt_set_tree(orc_rrt* r, const double* states, const int32_t* parents, uint32_t n) {
+    if (!r->is_setup) return ORC_PLANNER_UNINITIALISED;
+    if (n == 0 || n > r->max_nodes || parents[0] != -1) return ORC_BAD_ARG;
+    clear_tree(r);
+    for (uint32_t i = 0; i < n; ++i) push_node(r, states + (size_t)i * r->dim, (int64_t)parents[i]);
+    return ORC_SOLVED;
+}
+
 /* rrt.rs:90-116 */
 static int check_motion(const orc_rrt* r, const double* from, const double* to) {
     if (!r->is_setup) return 0; /* rrt.rs:113-115 */

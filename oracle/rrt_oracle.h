@@ -83,6 +83,8 @@ int orc_rrt_set_spheres(orc_rrt* r, const double* centres, const double* radii, 
 int orc_rrt_set_boxes(orc_rrt* r, const double* lo, const double* hi, uint32_t n);
 /* Planner::setup (rrt.rs:140-156) with a ball goal whose sample_goal() is the centre */
 int orc_rrt_setup(orc_rrt* r, const double* start, const double* goal_centre, double goal_radius);
+/* warm start: replace the tree by n nodes (AoS states, parents[0] = -1); counters / RNG untouched */
+int orc_rrt_set_tree(orc_rrt* r, const double* states, const int32_t* parents, uint32_t n);
 /* Planner::solve (rrt.rs:158-227) with a deterministic iteration budget.
  * freeze != 0: "steady" mode, inserts suppressed (tree size constant). */
 int orc_rrt_solve(orc_rrt* r, uint64_t max_iterations, int freeze, double timeout_s);

@@ -23,7 +23,7 @@ KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT = 0, 1, 2
 EXPORTS = [
     "oxhip_abi_version", "oxhip_status_string", "oxhip_last_error_string", "oxhip_device_count",
     "oxhip_rrt_batch_create", "oxhip_rrt_batch_destroy", "oxhip_rrt_batch_set_spheres",
-    "oxhip_rrt_batch_set_boxes", "oxhip_rrt_batch_setup", "oxhip_rrt_batch_solve",
+    "oxhip_rrt_batch_set_boxes", "oxhip_rrt_batch_setup", "oxhip_rrt_batch_set_tree", "oxhip_rrt_batch_solve",
     "oxhip_rrt_batch_get_counts", "oxhip_rrt_batch_get_tree", "oxhip_rrt_batch_get_path",
     "oxhip_rrt_batch_last_timing", "oxhip_rrt_batch_enable_stamps", "oxhip_rrt_batch_get_stamps",
     "oxhip_nn_argmin_batch", "oxhip_distance_batch",
@@ -88,6 +88,7 @@ def lib():
         L.oxhip_rrt_batch_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
         L.oxhip_rrt_batch_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
         L.oxhip_rrt_batch_setup.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.oxhip_rrt_batch_set_tree.argtypes = [C.c_void_p, C.c_uint32, _dp, _i32p, C.c_uint32]
         L.oxhip_rrt_batch_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_uint32, _i32p]
         L.oxhip_rrt_batch_get_counts.argtypes = [C.c_void_p, _u64p, _u32p, _u64p, _u64p, _i32p, _i32p]
         L.oxhip_rrt_batch_get_tree.argtypes = [C.c_void_p, C.c_uint32, _dp, _i32p, C.c_uint32, _u32p]
@@ -184,6 +185,11 @@ class RRTBatch:
         g = np.ascontiguousarray(np.broadcast_to(_f64(goal_centres).reshape(-1, self.dim), (P, self.dim)))
         r = np.ascontiguousarray(np.broadcast_to(_f64(goal_radii).reshape(-1), (P,)))
         _check(lib().oxhip_rrt_batch_setup(self._h, _p(s), _p(g), _p(r)))
+
+    def set_tree(self, problem, states, parents):
+        s = _f64(states).reshape(-1, self.dim)
+        par = np.ascontiguousarray(parents, dtype=np.int32)
+        _check(lib().oxhip_rrt_batch_set_tree(self._h, problem, _p(s), _p(par, _i32p), s.shape[0]))
 
     def solve(self, max_iterations, timeout_s=0.0, freeze=False):
         st = np.empty(self.n_problems, dtype=np.int32)

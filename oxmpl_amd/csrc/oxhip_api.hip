@@ -7,6 +7,7 @@
 // entry point that computes returns OXHIP_ERR_NO_DEVICE.
 #include "../../include/oxmpl_hip.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -373,6 +374,59 @@ static int32_t refresh_filter(oxhip_rrt_batch* b) {
     if (st != OXHIP_OK) return st;
     b->dp.sph_filt = b->sph_filt.p;
     b->filt_dirty = false;
+    return OXHIP_OK;
+}
+
+static int32_t read_states(oxhip_rrt_batch* b, std::vector<ProblemState>& states);
+
+int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const double* states_in, const int32_t* parents_in,
+                                 uint32_t n) {
+    if (!b || !states_in || !parents_in) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");
+    if (problem >= b->cfg.n_problems) return fail(OXHIP_ERR_BAD_ARG, "problem index out of range");
+    if (n == 0 || n > b->cfg.max_nodes) return fail(OXHIP_ERR_BAD_ARG, "n_nodes must be in 1..max_nodes");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    const uint32_t dim = b->cfg.dim, cap = b->dp.cap;
+    if (parents_in[0] != -1) return fail(OXHIP_ERR_BAD_ARG, "parents[0] must be -1 (the root)");
+    std::vector<double> soa((size_t)dim * n);
+    std::vector<uint8_t> skip(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i > 0 && (parents_in[i] < 0 || (uint32_t)parents_in[i] >= i)) return fail(OXHIP_ERR_BAD_ARG, "parent index must precede its child");
+        for (uint32_t k = 0; k < dim; ++k) {
+            double v = states_in[(size_t)i * dim + k];
+            if (!(std::fabs(v) <= kMaxMagnitude)) return fail(OXHIP_ERR_BAD_ARG, "state not finite or beyond 1e150");
+            soa[(size_t)k * n + i] = v;
+        }
+    }
+    // skip flag: a node whose coordinates equal (as values) those of a lower-index node can never be nearest
+    {
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        auto key_less = [&](uint32_t a, uint32_t c) {
+            for (uint32_t k = 0; k < dim; ++k) {
+                double x = soa[(size_t)k * n + a] + 0.0, y = soa[(size_t)k * n + c] + 0.0;  // -0.0 -> +0.0
+                if (x < y) return true;
+                if (y < x) return false;
+            }
+            return a < c;
+        };
+        std::sort(order.begin(), order.end(), key_less);
+        for (uint32_t j = 1; j < n; ++j) {
+            bool same = true;
+            for (uint32_t k = 0; k < dim && same; ++k) same = soa[(size_t)k * n + order[j]] == soa[(size_t)k * n + order[j - 1]];
+            if (same) skip[order[j]] = 1;  // order[j-1] has the lower index among equals (ties sort by index)
+        }
+    }
+    HIP_TRY(hipMemcpy2DAsync(b->tree.p + (size_t)problem * dim * cap, (size_t)cap * sizeof(double), soa.data(),
+                             (size_t)n * sizeof(double), (size_t)n * sizeof(double), dim, hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->parent.p + (size_t)problem * cap, parents_in, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->skip.p + (size_t)problem * cap, skip.data(), n, hipMemcpyHostToDevice, b->stream));
+    std::vector<ProblemState> states;
+    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    states[problem].n_nodes = n;
+    HIP_TRY(hipMemcpyAsync(b->state.p + problem, &states[problem], sizeof(ProblemState), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
     return OXHIP_OK;
 }
 

@@ -294,6 +294,8 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
             lo = rng.random((nb, dim)) * 6.0 - 1.0
             sc["boxes"] = (lo, lo + rng.random((nb, dim)) * 0.8 + 0.1)
         P = 6
+        if kernel == capi.KERNEL_RESIDENT and dim not in (2, 3):
+            continue  # the resident kernel is instantiated for R^2 / R^3 only
         gpu = _gpu_for(sc, P, 400, False, 7, 100, kernel)
         gpu.solve(500)
         planners = [_oracle_for(sc, 7, 100 + p, 400, False) for p in range(P)]
@@ -361,6 +363,82 @@ def test_rrt_termination_resume_and_freeze(kernel):
     assert (st == capi.ERR_TIMEOUT).all()
     c = gpu.counts()
     assert (c["stop_reason"] == capi.STOP_TIMEOUT).all() and (c["nodes"] == 1).all() and (c["accepted"] == 0).all()
+    gpu.close()
+
+
+def _d2(a, q):
+    acc = None
+    for x, y in zip(a, q):
+        d = x - y
+        acc = d * d if acc is None else acc + d * d
+    return acc
+
+
+def _near_tie_pair(q, rng):
+    """two states whose squared distances to q differ (by an ulp or two) but whose square roots
+    round to the same double: the reference (post-sqrt compare) must keep the LOWER index"""
+    for _ in range(200000):
+        v = rng.standard_normal(len(q))
+        a = [float(x + 0.9 * w / np.linalg.norm(v)) for x, w in zip(q, v)]
+        da = _d2(a, q)
+        b = list(a)
+        for _k in range(40):
+            b[-1] = float(np.nextafter(b[-1], np.inf))
+            db = _d2(b, q)
+            if db != da and math.sqrt(db) == math.sqrt(da):
+                return a, b, da, db
+    raise AssertionError("no near-tie pair found")
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+def test_planner_near_ties_take_the_exact_path(kernel):
+    """Plant, in each problem's tree, two nodes whose d2 to the problem's FIRST query differ but whose
+    sqrt coincide, at index pairs that land in one lane, in different lanes and in different waves
+    of both kernels; the reference's strict '<' on the post-sqrt value keeps the lower index even
+    when its d2 is the larger one.  One frozen iteration; nearest index is part of the checksum."""
+    sc = scenarios.config2()
+    sc["goal_bias"] = 0.0
+    pairs = [(1, 2), (5, 517), (5, 261), (70, 700), (2999, 17), (1030, 6), (64, 128), (511, 512), (2047, 2048)]
+    cases = [(ia, ib, swap) for ia, ib in pairs for swap in (False, True)]
+    P, n = len(cases), 3000
+    gpu = _gpu_for(sc, P, 4096, False, 77, 0, kernel)
+    rng = np.random.default_rng(123)
+    planners, flipped = [], 0
+    for p, (ia, ib, swap) in enumerate(cases):
+        r = orc.Rng(77, p)
+        assert not r.random_bool(0.0)
+        q = [r.random_range(lo, hi) for lo, hi in sc["bounds"]]
+        a, b, da, db = _near_tie_pair(q, rng)
+        if swap:
+            a, b, da, db = b, a, db, da
+        # every other node is at least 3 away from q
+        far = rng.standard_normal((n, 3))
+        far = np.array(q) + far / np.linalg.norm(far, axis=1, keepdims=True) * (3.0 + rng.random((n, 1)) * 4.0)
+        tree = far.copy()
+        tree[ia], tree[ib] = a, b
+        parents = np.concatenate([[-1], rng.integers(0, np.arange(1, n))]).astype(np.int32)
+        o = _oracle_for(sc, 77, p, 4096, False)
+        assert o.set_tree(tree, parents) == 0
+        gpu.set_tree(p, tree, parents)
+        planners.append(o)
+        lo_idx = min(ia, ib)
+        d_lo = da if ia < ib else db
+        d_hi = db if ia < ib else da
+        if d_lo > d_hi:
+            flipped += 1  # a d2-argmin would pick the other node
+        assert orc.nearest(tree, q)[0] == lo_idx
+    assert flipped >= 3
+    gpu.solve(1, freeze=True)
+    c = gpu.counts()
+    for p, o in enumerate(planners):
+        o.solve(1, freeze=True)
+        assert int(c["checksum"][p]) == o.checksum, cases[p]
+        assert int(c["nodes"][p]) == n
+    # and the warm-started trees keep growing identically
+    gpu.solve(300)
+    for p, o in enumerate(planners):
+        o.solve(300)
+        _assert_same_problem(gpu, p, o)
     gpu.close()
 
 
