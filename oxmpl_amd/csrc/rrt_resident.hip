@@ -27,7 +27,11 @@ __device__ __forceinline__ double dpp_min_step(double v) {
     // bound_ctrl = false + old = own value: lanes without a source keep their own value
     int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
     int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    return fmin(v, __hiloint2double(ohi, olo));
+    // plain v_min_f64: the operands are squared distances (never NaN), so the canonicalising
+    // v_max_f64 x,x that fmin() would add in front of every step is dead weight
+    double o = __hiloint2double(ohi, olo), r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
+    return r;
 }
 
 __device__ __forceinline__ double wave_min_f64(double v) {
@@ -90,19 +94,58 @@ struct WaveExact {
     double c[DIM];
 };
 
-// lane-predicated store of the owning lane's slot `slot` (wave-uniform) into LDS
+// lane-predicated store of the owning lane's slot `slot` (wave-uniform) into LDS.  Register arrays
+// cannot be indexed dynamically (the compiler would demote the whole tree to scratch), so the slot
+// is matched by uniform branches ending in compile-time indices: groups of 4, then the slot.
 template <int DIM, int S>
 __device__ __forceinline__ void store_slot(const double (&tr)[DIM][S], uint32_t slot, bool mine, double* dst) {
+    const uint32_t grp = slot >> 2, sub = slot & 3u;
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (slot == (uint32_t)s) {  // uniform branch; indices below are compile-time constants
-            if (mine) {
+    for (int g = 0; g < (S + 3) / 4; ++g) {
+        if (grp == (uint32_t)g) {  // uniform
 #pragma unroll
-                for (int k = 0; k < DIM; ++k) dst[k] = tr[k][s];
+            for (int t = 0; t < 4; ++t) {
+                if (4 * g + t < S) {
+                    if (sub == (uint32_t)t) {  // uniform
+                        if (mine) {
+#pragma unroll
+                            for (int k = 0; k < DIM; ++k) dst[k] = tr[k][4 * g + t];
+                        }
+                    }
+                }
             }
         }
     }
 }
+
+// Node -> (scanner thread, register slot).  Waves w, w+4, w+8 share a SIMD (waves are dealt to the
+// four SIMDs cyclically), so scanner waves 0 and 4 sit beside the resolver (wave 8) and would be
+// ~20 % slower than the other six.  The S = 21 layout therefore gives them 17 slots and the other
+// six waves 21: rows 0..16 span all 512 threads, rows 17..20 only the 384 threads of waves
+// 1,2,3,5,6,7 (17*512 + 4*384 = 10,240 nodes).  Smaller instantiations use the plain even layout.
+template <int S>
+struct Layout {
+    static constexpr bool kUneven = (S == 21);
+    static constexpr uint32_t kCommon = kUneven ? 17u : (uint32_t)S;   // rows every wave holds
+    static constexpr uint32_t kHeavyThreads = 384;
+    static constexpr uint32_t kCapacity = kUneven ? (17u * 512u + 4u * 384u) : (uint32_t)S * 512u;
+    __device__ static __forceinline__ bool heavy(uint32_t wave) { return !kUneven || (wave & 3u) != 0; }
+    __device__ static __forceinline__ uint32_t node_index(uint32_t wave, uint32_t lane, uint32_t slot) {
+        if (slot < kCommon) return slot * 512u + wave * 64u + lane;
+        const uint32_t hw = wave - 1u - (wave > 4u ? 1u : 0u);  // waves 1,2,3,5,6,7 -> 0..5
+        return kCommon * 512u + (slot - kCommon) * kHeavyThreads + hw * 64u + lane;
+    }
+    __device__ static __forceinline__ void locate(uint32_t i, uint32_t& thread, uint32_t& slot) {
+        if (i < kCommon * 512u) { thread = i & 511u; slot = i >> 9; return; }
+        const uint32_t r = i - kCommon * 512u, c = r % kHeavyThreads, hw = c >> 6;
+        slot = kCommon + r / kHeavyThreads;
+        thread = (hw + 1u + (hw >= 3u ? 1u : 0u)) * 64u + (c & 63u);
+    }
+    __device__ static __forceinline__ uint32_t slots_in_use(uint32_t wave, uint32_t n) {
+        if (n <= kCommon * 512u) return (n + 511u) >> 9;
+        return heavy(wave) ? kCommon + (n - kCommon * 512u + kHeavyThreads - 1u) / kHeavyThreads : kCommon;
+    }
+};
 
 // ------------------------------------------------------------------------------------------
 // Asynchronous pipeline.  kScanWaves scanner waves own the tree (node i in thread i % 512, slot
@@ -220,74 +263,69 @@ __device__ __forceinline__ bool steer_and_check(const DevParams& p, uint32_t lan
 }
 
 // Lane-parallel sampling of m <= 64 consecutive queries (rrt.rs:177-184 + rvss.rs:233-249): lane l
-// produces query js + l.  A query's position in the ChaCha stream depends on how many words the
-// earlier queries drew (1 for a goal sample, 1 + DIM otherwise, more after a rejected draw), so
-// the lanes start from the no-goal guess and iterate "draw -> exclusive prefix sum of the word
-// counts" to its fix-point (one extra round per goal-biased query in the batch, on average).
-// Returns false (nothing written) if a lane would read past the LDS word window; the caller
-// then samples sequentially.
+// produces query js + l.  A query starts where the earlier ones stopped drawing: a goal sample
+// takes 1 word, a uniform sample 1 + DIM.  So the word offset of lane l is
+// (1+DIM)*l - DIM*popcount(goal lanes below l): the lanes iterate "read my Bernoulli word at the
+// offset implied by the current goal mask -> ballot the new goal mask" to its fix-point (one extra
+// round per goal sample in the batch).  A rejected range draw (res >= hi, probability ~2^-53) or a
+// read past the LDS word window makes the function return false with nothing written; the caller
+// then samples that batch sequentially.
 template <int DIM>
 __device__ __forceinline__ bool sample_batch(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m,
                                              uint32_t lane, QSlot<DIM>* qring, uint32_t js) {
-    const uint64_t win_lo = rng.base_blk * 8, win_hi = win_lo + 512;
+    const uint64_t win_lo = rng.base_blk * 8;
     const uint64_t pos0 = rng.pos;
-    if (pos0 < win_lo || pos0 >= win_hi) return false;
-    const bool always_goal = p.p_int == ~0ull;
+    if (pos0 < win_lo || pos0 + (uint64_t)m * (1 + DIM) > win_lo + 512) return false;
+    const uint32_t rel0 = (uint32_t)(pos0 - win_lo);  // first word of the batch inside the window
     const bool act = lane < m;
-    uint32_t off = always_goal ? 0u : lane * (1u + (uint32_t)DIM);  // guess: nobody before me sampled the goal
-    double q[DIM];
-    uint32_t cnt = 0;
-    bool overflow = false;
-    for (uint32_t round = 0; round <= m; ++round) {
-        uint32_t at = off;
-        auto word = [&](uint32_t rel) -> uint64_t {
-            const uint64_t a = pos0 + rel;
-            if (a >= win_hi) { overflow = true; return 0; }
-            const uint32_t bl = (uint32_t)((a >> 3) - rng.base_blk), w = (uint32_t)(a & 7) * 2;
-            return ((uint64_t)rng.buf[w + 1][bl] << 32) | rng.buf[w][bl];
-        };
-        bool goal = always_goal;
-        if (!always_goal) goal = word(at++) < p.p_int;
-        if (goal) {
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) q[k] = goal_c[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-                double res;
-                for (;;) {
-                    const uint64_t bits = (word(at++) >> 12) | 0x3FF0000000000000ull;
-                    const double v01 = __longlong_as_double((long long)bits) - 1.0;
-                    res = v01 * p.scale[k];
-                    res = res + p.lo[k];
-                    if (res < p.hi[k] || overflow) break;
-                }
-                q[k] = res;
-            }
+    const bool always_goal = p.p_int == ~0ull;
+    auto word = [&](uint32_t rel) -> uint64_t {       // rel < 512 by the check above
+        const uint32_t a = rel0 + rel, bl = a >> 3, w = (a & 7u) * 2u;
+        return ((uint64_t)rng.buf[w + 1][bl] << 32) | rng.buf[w][bl];
+    };
+    uint64_t goal_mask = always_goal ? ~0ull : 0ull;
+    uint32_t off = 0;
+    if (!always_goal) {
+        const uint64_t below = (1ull << lane) - 1ull;
+        for (uint32_t round = 0; round <= m; ++round) {
+            off = act ? (1u + DIM) * lane - (uint32_t)DIM * (uint32_t)__popcll(goal_mask & below) : 0u;
+            const uint64_t now = __ballot(act && word(off) < p.p_int);
+            if (now == goal_mask) break;
+            goal_mask = now;
         }
-        cnt = act ? (at - off) : 0u;
-        // exclusive prefix sum of cnt over the lanes
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-            if ((int)lane >= d) incl += o;
-        }
-        const uint32_t true_off = incl - cnt;
-        const bool same = !act || true_off == off;
-        off = true_off;
-        if (__ballot(!same) == 0) break;
     }
-    if (__ballot(act && overflow) != 0) return false;
+    const bool goal = (goal_mask >> lane) & 1ull;
+    double q[DIM];
+    bool redraw = false;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const uint64_t bits = (word(act && !goal ? off + 1u + (uint32_t)k : 0u) >> 12) | 0x3FF0000000000000ull;
+        const double v01 = __longlong_as_double((long long)bits) - 1.0;
+        double res = v01 * p.scale[k];
+        res = res + p.lo[k];
+        redraw = redraw || !(res < p.hi[k]);
+        q[k] = goal ? goal_c[k] : res;
+    }
+    if (__ballot(act && !goal && redraw) != 0) return false;
+    const uint32_t cnt = always_goal ? 0u : (goal ? 1u : 1u + (uint32_t)DIM);
     if (act) {
         QSlot<DIM>& qs = qring[(js + lane) & (kRing - 1)];
 #pragma unroll
         for (int k = 0; k < DIM; ++k) qs.q[k] = q[k];
         qs.pos_after = pos0 + off + cnt;
     }
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), (int)(m - 1));
-    rng.pos = pos0 + total;
+    rng.pos = pos0 + (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), (int)(m - 1));
     return true;
+}
+
+// scan groups: kGroup slots per uniform branch, never straddling the common / heavy-only boundary
+template <int S>
+__host__ __device__ constexpr int group_len(int g0) {
+    const int common = (int)Layout<S>::kCommon;
+    int len = kGroup;
+    if (g0 < common && g0 + len > common) len = common - g0;
+    if (g0 + len > S) len = S - g0;
+    return len;
 }
 
 template <int DIM, int S, bool STAMP>
@@ -319,11 +357,12 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
 
     if (wave < kScanWaves) {
         // ================================================================= scanner waves
+        using Lay = Layout<S>;
         uint32_t n_local = st0.n_nodes;
         double tr[DIM][S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            uint32_t i = tid + kScanThreads * s;
+            const uint32_t i = ((uint32_t)s < Lay::kCommon || Lay::heavy(wave)) ? Lay::node_index(wave, lane, (uint32_t)s) : kNoNode;
             const bool live = i < n_local && skip[i] == 0;  // duplicates of a lower-index node never win: hold +inf
 #pragma unroll
             for (int k = 0; k < DIM; ++k) tr[k][s] = live ? tree[(size_t)k * cap + i] : __builtin_inf();
@@ -346,8 +385,9 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
             // absorb the nodes committed since this wave's last snapshot (the owner lane takes each)
             const uint32_t nc = uni(lds_peek(&sh.committed));
             for (uint32_t i = n_local; i < nc; ++i) {
-                const uint32_t sl = i / kScanThreads;
-                const bool mine = tid == (i % kScanThreads);
+                uint32_t owner_thread, sl;
+                Lay::locate(i, owner_thread, sl);
+                const bool mine = tid == owner_thread;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     if (sl == (uint32_t)s) {
@@ -367,7 +407,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                 for (int k = 0; k < D; ++k) q[b][k] = unid(sh.qring[slot].q[k]);
             }
             // nearest neighbour over this wave's nodes (rrt.rs:187-196), d2 compare
-            const uint32_t nslots = (nc + kScanThreads - 1) / kScanThreads;
+            const uint32_t nslots = Lay::slots_in_use(wave, nc);
             Scan sc[kBatch];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) sc[b] = Scan{__builtin_inf(), 0u, 0xFFFFFFFFu};
@@ -375,10 +415,10 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
             // straight-line, so the scheduler interleaves kGroup x kBatch independent sub/mul/add chains
             // (empty slots hold +inf and can never win)
 #pragma unroll
-            for (int g0 = 0; g0 < S; g0 += kGroup) {
+            for (int g0 = 0; g0 < S; g0 += group_len<S>(g0)) {
                 if ((uint32_t)g0 < nslots) {
 #pragma unroll
-                    for (int s = g0; s < g0 + kGroup && s < S; ++s) {
+                    for (int s = g0; s < g0 + group_len<S>(g0); ++s) {
                         double c[D];
 #pragma unroll
                         for (int k = 0; k < D; ++k) c[k] = tr[k][s];
@@ -402,7 +442,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                     store_slot<DIM, S>(tr, wslot, (int)lane == wl, out.c);
                     if (lane == 0) {
                         out.b1 = wmin;
-                        out.i1 = (wave << 6) + (uint32_t)wl + wslot * kScanThreads;
+                        out.i1 = Lay::node_index(wave, (uint32_t)wl, wslot);
                         out.amb = wamb;
                         sh.base_n[slot][wave] = nc;
                         lds_bump(&sh.done[slot]);
@@ -601,7 +641,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
 static int pick_slots(uint32_t cap) {
     const uint32_t need = (cap + kScanThreads - 1) / kScanThreads;
     if (need <= 4) return 4;
-    if (need <= 20) return 20;
+    if (cap <= Layout<21>::kCapacity) return 21;
     return 0;
 }
 
@@ -616,9 +656,9 @@ void launch_rrt_resident(const DevParams& p, hipStream_t stream) {
         else hipLaunchKernelGGL((rrt_resident_kernel<DIM_, S_, false>), grid, block, 0, stream, p);         \
     } while (0)
     if (p.dim == 3) {
-        if (s == 4) OXHIP_LAUNCH(3, 4); else OXHIP_LAUNCH(3, 20);
+        if (s == 4) OXHIP_LAUNCH(3, 4); else OXHIP_LAUNCH(3, 21);
     } else {
-        if (s == 4) OXHIP_LAUNCH(2, 4); else OXHIP_LAUNCH(2, 20);
+        if (s == 4) OXHIP_LAUNCH(2, 4); else OXHIP_LAUNCH(2, 21);
     }
 #undef OXHIP_LAUNCH
 }

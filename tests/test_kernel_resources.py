@@ -1,0 +1,56 @@
+"""CPU: compile the resident kernel to gfx950 ISA (no GPU needed) and check the properties the
+design depends on: the tree stays in VGPRs (no spill, no demotion of the register array to a
+dynamically indexed scratch array), the arithmetic is unfused, the launch geometry fits the CU."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "oxmpl_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def resident_asm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("asm") / "rrt_resident.s")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "rrt_resident.hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernels(asm):
+    """name -> metadata dict from the amdhsa.kernels YAML block"""
+    meta = {}
+    for block in asm.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        meta[name] = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|"
+                                                        r"private_segment_fixed_size|group_segment_fixed_size|"
+                                                        r"max_flat_workgroup_size):\s+(\d+)", block)}
+    return meta
+
+
+def test_resident_tree_stays_in_registers(resident_asm):
+    meta = {k: v for k, v in _kernels(resident_asm).items() if "rrt_resident_kernel" in k}
+    assert len(meta) == 8  # dim {2,3} x slots {4,21} x {product, stamped diagnostic}
+    for name, m in meta.items():
+        assert m["vgpr_spill_count"] == 0, name
+        # a demoted tr[DIM][S] array would need >= 8*DIM*S bytes of scratch (>= 192 B); the fixed 40 B is
+        # the ChaCha block's word buffer
+        assert m["private_segment_fixed_size"] <= 64, (name, m)
+        assert m["max_flat_workgroup_size"] == 576
+        # 9 waves per CU -> at most 3 on a SIMD -> 512/3 = 170 registers per lane
+        assert m["vgpr_count"] <= 168, (name, m)
+        assert m["group_segment_fixed_size"] <= 16 * 1024
+    big = [m for k, m in meta.items() if "Li3ELi21ELb0" in k][0]
+    assert big["vgpr_count"] >= 126  # 21 slots x 3 x f64 = 126 VGPRs of tree alone
+
+
+def test_resident_scan_arithmetic_is_unfused(resident_asm):
+    body = resident_asm.split("rrt_resident_kernelILi3ELi21ELb0EEEvNS_9DevParamsE:")[1].split("s_endpgm")[0]
+    n_mul, n_add, n_fma = body.count("v_mul_f64"), body.count("v_add_f64"), body.count("v_fma_f64")
+    assert n_mul > 200 and n_add > 300          # the unrolled sub/mul/add scan
+    assert n_fma < n_mul // 4                   # FMAs appear only inside the sqrt / division expansions
+    assert "v_med3_u32" in body and "row_bcast:31" in body and "s_setprio" in body
