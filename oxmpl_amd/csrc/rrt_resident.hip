@@ -80,10 +80,11 @@ __device__ __forceinline__ void scan_push(Scan& v, double d, uint32_t s) {
 }
 
 template <int DIM>
-struct WavePub {      // one wave's nearest-neighbour candidate
+struct alignas(16) WavePub {  // one wave's nearest-neighbour candidate (head = one 16-byte LDS store)
     double b1;        // its smallest d2
     uint32_t i1;      // lowest index attaining it
-    uint32_t amb;     // the wave saw another d2 whose high dword is within 1 of b1's
+    uint32_t amb_nc;  // bit 0: the wave saw another d2 whose high dword is within 1 of b1's;
+                      // bits 1..: the tree size this scan covered (the wave's snapshot of `committed`)
     double c[DIM];    // the candidate's coordinates (written by the owning lane)
 };
 template <int DIM>
@@ -175,7 +176,6 @@ struct PipeShared {
     uint32_t rng_buf[16][64];
     QSlot<DIM> qring[kRing];
     WavePub<DIM> pub[kRing][kScanWaves];
-    uint32_t base_n[kRing][kScanWaves];  // tree size each wave's scan covered
     uint32_t done[kRing];                // scanner waves that have published this slot
     double newn[64][DIM];                // the last 64 committed nodes, node i at i & 63
     uint32_t sampled;                    // queries sampled so far   (monotonic)
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
 #pragma unroll
             for (int k = 0; k < DIM; ++k) tr[k][s] = live ? tree[(size_t)k * cap + i] : __builtin_inf();
         }
-        uint64_t t_wait = 0, t_work = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
+        uint64_t t_wait = 0, t_work = 0, t_pre = 0, t_scan = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
         uint32_t seen_sampled = 0;
         for (uint32_t j = 0; j < budget; j += kBatch) {
             // one pass scans kBatch queries (the tail pass may hold one): fixed costs are shared, the two
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
             Scan sc[kBatch];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) sc[b] = Scan{__builtin_inf(), 0u, 0xFFFFFFFFu};
+            if (STAMP) { uint64_t now = (uint64_t)clock64(); t_pre += now - t_mark; t_mark = now; }
             // slots are visited in groups of kGroup under ONE uniform branch: inside a group the code is
             // straight-line, so the scheduler interleaves kGroup x kBatch independent sub/mul/add chains
             // (empty slots hold +inf and can never win)
@@ -427,24 +428,33 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                     }
                 }
             }
+            if (STAMP) { uint64_t now = (uint64_t)clock64(); t_scan += now - t_mark; t_mark = now; }
+            // reduce: branch-free for the whole batch, so the kBatch DPP chains / ballots interleave
+            double wmin[kBatch];
+            int wl[kBatch];
+            uint32_t wslot[kBatch], wamb[kBatch];
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) wmin[b] = wave_min_f64(sc[b].b1);
+#pragma unroll
+            for (int b = 0; b < kBatch; ++b) {
+                const uint64_t eqm = __ballot(sc[b].b1 == wmin[b]);
+                wl[b] = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
+                wslot[b] = __builtin_amdgcn_readlane(sc[b].slot, wl[b]);
+                const uint32_t hb = hi32(wmin[b]) + 1;
+                const bool amb_l = ((int)lane != wl[b] && hi32(sc[b].b1) <= hb) || (sc[b].h2 <= hb);
+                wamb[b] = __ballot(amb_l) != 0 ? 1u : 0u;
+            }
+            // publish: the owning lane stores the coordinates, lane 0 the 16-byte head, then the slot is counted
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
                 if ((uint32_t)b < nb) {
                     const uint32_t slot = (j + (uint32_t)b) & (kRing - 1);
-                    const double wmin = wave_min_f64(sc[b].b1);
-                    const uint64_t eqm = __ballot(sc[b].b1 == wmin);
-                    const int wl = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
-                    const uint32_t wslot = __builtin_amdgcn_readlane(sc[b].slot, wl);
-                    const uint32_t hb = hi32(wmin) + 1;
-                    const bool amb_l = ((int)lane != wl && hi32(sc[b].b1) <= hb) || (sc[b].h2 <= hb);
-                    const uint32_t wamb = __ballot(amb_l) != 0 ? 1u : 0u;
                     WavePub<DIM>& out = sh.pub[slot][wave];
-                    store_slot<DIM, S>(tr, wslot, (int)lane == wl, out.c);
+                    store_slot<DIM, S>(tr, wslot[b], (int)lane == wl[b], out.c);
                     if (lane == 0) {
-                        out.b1 = wmin;
-                        out.i1 = Lay::node_index(wave, (uint32_t)wl, wslot);
-                        out.amb = wamb;
-                        sh.base_n[slot][wave] = nc;
+                        out.b1 = wmin[b];
+                        out.i1 = Lay::node_index(wave, (uint32_t)wl[b], wslot[b]);
+                        out.amb_nc = (nc << 1) | wamb[b];
                         lds_bump(&sh.done[slot]);
                     }
                 }
@@ -453,7 +463,8 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         }
         if (STAMP && p.dbg && prob == 0 && lane == 0) {
             p.dbg[16 + wave] = t_wait;
-            p.dbg[24 + wave] = t_work;
+            p.dbg[24 + wave] = t_work + t_pre + t_scan;
+            if (wave == 5) { p.dbg[8] = t_pre; p.dbg[9] = t_scan; p.dbg[10] = t_work; }
         }
         return;
     }
@@ -533,9 +544,10 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         const bool inS = lane < (uint32_t)kScanWaves;
         const WavePub<DIM>& mine = sh.pub[slot][inS ? lane : 0];
         const double pb = inS ? mine.b1 : __builtin_inf();
-        const uint32_t pamb = inS ? mine.amb : 0u;
+        const uint32_t pan = inS ? mine.amb_nc : 0xFFFFFFFFu;
+        const uint32_t pamb = inS ? (pan & 1u) : 0u;
         const uint32_t pidxS = inS ? mine.i1 : kNoNode;
-        const uint32_t base_min = wave_min_u32(inS ? sh.base_n[slot][lane] : kNoNode);
+        const uint32_t base_min = wave_min_u32(pan >> 1);  // oldest snapshot among the 8 scans
         const bool pv = pidx != kNoNode && pidx >= base_min;
         const double d2p = pv ? dist2<D>(pn, q, DIM) : __builtin_inf();
         const double g = wave_min_f64(d2p < pb ? d2p : pb);  // one reduction over both candidate kinds

@@ -20,3 +20,4 @@ print("resolver wave: sample %.0f  wait-for-scanners %.0f  resolve+commit %.0f  
 print("   of which combine %.0f cyc/iter; exact-path events %d of %d" % (int(s[3]) / iters, int(s[4]), iters))
 print("scanner waves: wait   ", " ".join("%6.0f" % (int(v) / iters) for v in s[16:24]))
 print("               scan   ", " ".join("%6.0f" % (int(v) / iters) for v in s[24:32]))
+print("scanner wave 5 per query: pre (absorb, q loads) %.0f  scan %.0f  reduce+publish %.0f cyc" % (int(s[8]) / iters, int(s[9]) / iters, int(s[10]) / iters))
