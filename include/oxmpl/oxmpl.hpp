@@ -1,0 +1,251 @@
+// oxmpl.hpp -- C++17 host side of the drop-in boundary: the reference's trait surface for the RRT
+// path, over the C ABI of include/oxmpl_hip.h.  Header-only; link with liboxmpl_hip.so.
+//
+// Names, argument meaning and error behaviour follow the reference (rossng/oxmpl, Rust):
+//   oxmpl::base::RealVectorState            oxmpl/src/base/states/real_vector_state.rs:5-13
+//   oxmpl::base::RealVectorStateSpace       oxmpl/src/base/spaces/real_vector_state_space.rs:65-129,137-186
+//   oxmpl::base::StateValidityChecker       oxmpl/src/base/validity.rs:39-48
+//   oxmpl::base::Goal / GoalRegion / GoalSampleableRegion   oxmpl/src/base/goal.rs:12-41
+//   oxmpl::base::ProblemDefinition, Path    oxmpl/src/base/problem_definition.rs:16-20, planner.rs:16-17
+//   oxmpl::base::PlanningError, StateSpaceError             oxmpl/src/base/error.rs:28-52,97-108
+//   oxmpl::geometric::RRT                   oxmpl/src/geometric/planners/rrt.rs:53-83,140-227
+//
+// Rust's Result<T, E> becomes oxmpl::Result<T, E> (value or error, never an exception), Arc<T>
+// becomes std::shared_ptr<T>.  Everything that computes runs on the GPU through the C ABI: there is
+// no CPU fallback here.  A validity checker / goal must be device-describable (spheres + boxes, a
+// ball); the planner refuses anything else with PlanningError::PlannerUninitialised at solve().
+#pragma once
+
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <memory>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "../oxmpl_hip.h"
+
+namespace oxmpl {
+
+template <typename T, typename E>
+class Result {
+  public:
+    Result(T v) : v_(std::move(v)) {}                      // NOLINT: Ok(v)
+    Result(E e) : v_(std::move(e)) {}                      // NOLINT: Err(e)
+    bool is_ok() const { return v_.index() == 0; }
+    bool is_err() const { return !is_ok(); }
+    T& unwrap() { return std::get<0>(v_); }
+    const T& unwrap() const { return std::get<0>(v_); }
+    const E& err() const { return std::get<1>(v_); }
+
+  private:
+    std::variant<T, E> v_;
+};
+
+namespace base {
+
+// ---- error.rs
+enum class PlanningError { Timeout, NoSolutionFound, PlannerUninitialised, InvalidStartState, UnsampledStateSpace };
+inline const char* to_string(PlanningError e) {
+    switch (e) {
+        case PlanningError::Timeout: return "Planner timed out.";
+        case PlanningError::NoSolutionFound: return "No solution found.";
+        case PlanningError::PlannerUninitialised: return "Planner was not set up before calling solve.";
+        case PlanningError::InvalidStartState: return "Start state is invalid.";
+        default: return "State space has not been sampled.";
+    }
+}
+struct StateSpaceError {
+    enum Kind { DimensionMismatch, InvalidBound, ZeroDimensionUnbounded } kind;
+    std::size_t expected = 0, found = 0;
+    double lower = 0.0, upper = 0.0;
+    bool operator==(const StateSpaceError& o) const { return kind == o.kind; }
+};
+
+// ---- states/real_vector_state.rs
+struct RealVectorState {
+    std::vector<double> values;
+    RealVectorState() = default;
+    explicit RealVectorState(std::vector<double> v) : values(std::move(v)) {}
+    bool operator==(const RealVectorState& o) const { return values == o.values; }
+};
+
+// ---- spaces/real_vector_state_space.rs
+class RealVectorStateSpace {
+  public:
+    std::size_t dimension = 0;
+    std::vector<std::pair<double, double>> bounds;
+    double longest_valid_segment_fraction = 0.05;
+
+    // RealVectorStateSpace::new (rvss.rs:65-100): bounds == nullptr means unbounded in every dimension
+    static Result<RealVectorStateSpace, StateSpaceError> create(std::size_t dimension,
+                                                                const std::vector<std::pair<double, double>>* bounds_option) {
+        RealVectorStateSpace s;
+        s.dimension = dimension;
+        if (bounds_option) {
+            if (bounds_option->size() != dimension)
+                return StateSpaceError{StateSpaceError::DimensionMismatch, dimension, bounds_option->size()};
+            for (auto& b : *bounds_option)
+                if (b.first >= b.second) return StateSpaceError{StateSpaceError::InvalidBound, 0, 0, b.first, b.second};
+            s.bounds = *bounds_option;
+        } else {
+            if (dimension == 0) return StateSpaceError{StateSpaceError::ZeroDimensionUnbounded};
+            const double inf = std::numeric_limits<double>::infinity();
+            s.bounds.assign(dimension, {-inf, inf});
+        }
+        return s;
+    }
+    // rvss.rs:121-129
+    void set_longest_valid_segment_fraction(double fraction) {
+        if (fraction > 0.0 && fraction <= 1.0) longest_valid_segment_fraction = fraction;
+        else if (fraction <= 0.0) longest_valid_segment_fraction = 0.0;
+        else longest_valid_segment_fraction = 1.0;
+    }
+    // StateSpace::distance (rvss.rs:137-155), evaluated by the HIP library (oxhip_distance_batch)
+    double distance(const RealVectorState& a, const RealVectorState& b, int device = 0) const {
+        double out = std::numeric_limits<double>::quiet_NaN();
+        if (a.values.size() == dimension && b.values.size() == dimension)
+            (void)oxhip_distance_batch(device, (uint32_t)dimension, a.values.data(), b.values.data(), 1, &out);
+        return out;
+    }
+    // StateSpace::interpolate (rvss.rs:161-186), evaluated by the HIP library (oxhip_interpolate_batch)
+    void interpolate(const RealVectorState& from, const RealVectorState& to, double t, RealVectorState& out_state,
+                     int device = 0) const {
+        out_state.values.assign(dimension, std::numeric_limits<double>::quiet_NaN());
+        (void)oxhip_interpolate_batch(device, (uint32_t)dimension, from.values.data(), to.values.data(), &t, 1,
+                                      out_state.values.data());
+    }
+};
+
+// ---- validity.rs: the reference's trait plus what a device-describable checker exposes
+struct Sphere { std::vector<double> centre; double radius; };   // valid iff distance(centre, p) > radius
+struct Box { std::vector<double> lo, hi; };                      // invalid iff lo_k <= p_k <= hi_k for all k
+class StateValidityChecker {
+  public:
+    virtual ~StateValidityChecker() = default;
+    // is_valid (validity.rs:39-48) is answered on the device from the description below
+    virtual std::vector<Sphere> spheres() const { return {}; }
+    virtual std::vector<Box> boxes() const { return {}; }
+};
+
+// ---- goal.rs: Goal / GoalRegion / GoalSampleableRegion collapsed onto the device-describable ball goal
+class GoalSampleableRegion {
+  public:
+    virtual ~GoalSampleableRegion() = default;
+    virtual RealVectorState target() const = 0;   // sample_goal() returns this state (README.md:160-162)
+    virtual double radius() const = 0;            // is_satisfied(s) = distance(s, target) <= radius
+};
+
+// ---- problem_definition.rs / planner.rs
+struct ProblemDefinition {
+    std::shared_ptr<RealVectorStateSpace> space;
+    std::vector<RealVectorState> start_states;
+    std::shared_ptr<GoalSampleableRegion> goal;
+};
+struct Path { std::vector<RealVectorState> states; };   // Path(pub Vec<S>)
+
+}  // namespace base
+
+namespace geometric {
+
+// RRT (rrt.rs:53-62) for one planning problem, grown on the GPU.
+class RRT {
+  public:
+    double max_distance;
+    double goal_bias;
+    // build-defined termination and RNG key (the reference stops on wall clock only and cannot be seeded)
+    uint32_t max_nodes = 10000;
+    uint64_t seed = 0;
+    uint64_t problem_id = 0;
+    int device = 0;
+
+    RRT(double max_distance_, double goal_bias_) : max_distance(max_distance_), goal_bias(goal_bias_) {}  // rrt.rs:75-83
+    ~RRT() { reset(); }
+    RRT(const RRT&) = delete;
+    RRT& operator=(const RRT&) = delete;
+
+    // Planner::setup (rrt.rs:140-156)
+    void setup(std::shared_ptr<base::ProblemDefinition> problem_def, std::shared_ptr<base::StateValidityChecker> validity_checker) {
+        reset();
+        pd_ = std::move(problem_def);
+        vc_ = std::move(validity_checker);
+        last_status_ = OXHIP_OK;
+        if (!pd_ || !vc_ || !pd_->space || !pd_->goal || pd_->start_states.empty()) { last_status_ = OXHIP_ERR_BAD_ARG; return; }
+        const auto& sp = *pd_->space;
+        oxhip_rrt_config cfg{};
+        cfg.struct_size = sizeof cfg;
+        cfg.dim = (uint32_t)sp.dimension;
+        for (std::size_t k = 0; k < sp.bounds.size() && k < OXHIP_MAX_DIM; ++k) {
+            cfg.bounds[2 * k] = sp.bounds[k].first;
+            cfg.bounds[2 * k + 1] = sp.bounds[k].second;
+        }
+        cfg.max_distance = max_distance;
+        cfg.goal_bias = goal_bias;
+        cfg.lvs_fraction = sp.longest_valid_segment_fraction;
+        cfg.n_problems = 1;
+        cfg.max_nodes = max_nodes;
+        cfg.stop_at_goal = 1;
+        cfg.kernel = OXHIP_KERNEL_AUTO;
+        cfg.seed = seed;
+        cfg.first_problem_id = problem_id;
+        cfg.device = device;
+        if ((last_status_ = oxhip_rrt_batch_create(&cfg, &batch_)) != OXHIP_OK) return;
+        std::vector<double> c, r, lo, hi;
+        for (auto& s : vc_->spheres()) { c.insert(c.end(), s.centre.begin(), s.centre.end()); r.push_back(s.radius); }
+        for (auto& b : vc_->boxes()) { lo.insert(lo.end(), b.lo.begin(), b.lo.end()); hi.insert(hi.end(), b.hi.begin(), b.hi.end()); }
+        if (!r.empty() && (last_status_ = oxhip_rrt_batch_set_spheres(batch_, c.data(), r.data(), (uint32_t)r.size())) != OXHIP_OK) return;
+        if (!lo.empty() && (last_status_ = oxhip_rrt_batch_set_boxes(batch_, lo.data(), hi.data(), (uint32_t)(lo.size() / sp.dimension))) != OXHIP_OK) return;
+        const auto target = pd_->goal->target();
+        const double radius = pd_->goal->radius();
+        last_status_ = oxhip_rrt_batch_setup(batch_, pd_->start_states[0].values.data(), target.values.data(), &radius);
+    }
+
+    // Planner::solve (rrt.rs:158-227)
+    Result<base::Path, base::PlanningError> solve(std::chrono::duration<double> timeout) {
+        if (!batch_ || last_status_ != OXHIP_OK) return base::PlanningError::PlannerUninitialised;  // rrt.rs:160-163
+        int32_t st = OXHIP_ERR_NO_SOLUTION_FOUND;
+        last_status_ = oxhip_rrt_batch_solve(batch_, 1ull << 40, timeout.count(), 0, &st);
+        if (last_status_ == OXHIP_ERR_PLANNER_UNINITIALISED) return base::PlanningError::PlannerUninitialised;
+        if (last_status_ != OXHIP_OK) return base::PlanningError::NoSolutionFound;
+        if (st == OXHIP_ERR_TIMEOUT) return base::PlanningError::Timeout;
+        if (st != OXHIP_OK) return base::PlanningError::NoSolutionFound;
+        uint32_t len = 0;
+        (void)oxhip_rrt_batch_get_path(batch_, 0, nullptr, 0, &len);
+        const std::size_t dim = pd_->space->dimension;
+        std::vector<double> flat((std::size_t)len * dim);
+        if ((last_status_ = oxhip_rrt_batch_get_path(batch_, 0, flat.data(), len, &len)) != OXHIP_OK)
+            return base::PlanningError::NoSolutionFound;
+        base::Path path;
+        for (uint32_t i = 0; i < len; ++i)
+            path.states.emplace_back(std::vector<double>(flat.begin() + i * dim, flat.begin() + (i + 1) * dim));
+        return path;
+    }
+
+    // batched StateValidityChecker::is_valid / RRT::check_motion on the device (test helpers)
+    bool is_valid(const base::RealVectorState& s) const {
+        uint8_t ok = 0;
+        if (batch_) (void)oxhip_rrt_batch_is_valid(batch_, s.values.data(), 1, &ok);
+        return ok != 0;
+    }
+    uint32_t num_nodes() const {
+        uint32_t n = 0;
+        if (batch_) (void)oxhip_rrt_batch_get_counts(batch_, nullptr, &n, nullptr, nullptr, nullptr, nullptr);
+        return n;
+    }
+    int32_t last_status() const { return last_status_; }
+
+  private:
+    void reset() {
+        if (batch_) (void)oxhip_rrt_batch_destroy(batch_);
+        batch_ = nullptr;
+    }
+    oxhip_rrt_batch* batch_ = nullptr;
+    std::shared_ptr<base::ProblemDefinition> pd_;
+    std::shared_ptr<base::StateValidityChecker> vc_;
+    int32_t last_status_ = OXHIP_ERR_PLANNER_UNINITIALISED;
+};
+
+}  // namespace geometric
+}  // namespace oxmpl

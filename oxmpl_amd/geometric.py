@@ -1,0 +1,71 @@
+"""Mirror of `oxmpl_py.geometric` (reference: oxmpl-py/src/geometric/rrt.rs:30-136) for the GPU path.
+
+    planner = RRT(max_distance=0.5, goal_bias=0.05, problem_definition=problem_def)
+    planner.setup(SphereBoxValidityChecker(...))
+    path = planner.solve(timeout_secs=5.0)      # -> Path; raises Exception(str) like the reference
+
+`RRTBatch` (oxmpl_amd.capi) is the batched form the benchmark uses; this class is the one-problem
+drop-in for users of the reference's Python API.
+"""
+import numpy as np
+
+from . import capi
+from .base import Path, ProblemDefinition, RealVectorState, SphereBoxValidityChecker
+
+_MESSAGES = {  # Display strings of PlanningError (oxmpl/src/base/error.rs:110-136)
+    capi.ERR_TIMEOUT: "Planner timed out.",
+    capi.ERR_NO_SOLUTION_FOUND: "No solution found.",
+    capi.ERR_PLANNER_UNINITIALISED: "Planner was not set up before calling solve.",
+}
+
+
+class RRT:
+    def __init__(self, max_distance, goal_bias, problem_definition, max_nodes=10000, seed=0, problem_id=0, device=0):
+        if not isinstance(problem_definition, ProblemDefinition):
+            raise TypeError("problem_definition must be a ProblemDefinition")
+        self.max_distance, self.goal_bias = float(max_distance), float(goal_bias)
+        self._pd = problem_definition
+        self._opts = dict(max_nodes=max_nodes, seed=seed, first_problem_id=problem_id, device=device)
+        self._batch = None
+
+    def setup(self, validity_checker):
+        """Planner::setup (rrt.rs:140-156).  The reference takes a Python callable here; the GPU path
+        takes a SphereBoxValidityChecker (see oxmpl_amd.base)."""
+        if not isinstance(validity_checker, SphereBoxValidityChecker):
+            raise TypeError("the GPU path cannot call a Python function per interpolated state; "
+                            "describe the obstacles with oxmpl_amd.base.SphereBoxValidityChecker")
+        pd = self._pd
+        if self._batch is not None:
+            self._batch.close()
+        try:
+            b = capi.RRTBatch(pd.space.dimension, pd.space.bounds, self.max_distance, self.goal_bias, 1,
+                              lvs_fraction=pd.space.longest_valid_segment_fraction, stop_at_goal=True, **self._opts)
+        except capi.OxhipError as e:
+            if e.status in (capi.ERR_UNBOUNDED, capi.ERR_ZERO_VOLUME, capi.ERR_BAD_ARG):
+                raise ValueError(str(e)) from None
+            raise
+        if validity_checker.spheres:
+            b.set_spheres([c for c, _ in validity_checker.spheres], [r for _, r in validity_checker.spheres])
+        if validity_checker.boxes:
+            b.set_boxes([lo for lo, _ in validity_checker.boxes], [hi for _, hi in validity_checker.boxes])
+        b.setup(pd.start_state.values, pd.goal.target.values, float(pd.goal.radius))
+        self._batch = b
+        self._checker = validity_checker
+
+    def solve(self, timeout_secs):
+        """Planner::solve (rrt.rs:158-227); errors surface as Exception(message) like the reference
+        (oxmpl-py/src/geometric/rrt.rs:117)."""
+        if self._batch is None:
+            raise Exception(_MESSAGES[capi.ERR_PLANNER_UNINITIALISED])
+        st = self._batch.solve(1 << 40, timeout_s=float(timeout_secs))
+        if st[0] != capi.OK:
+            raise Exception(_MESSAGES.get(int(st[0]), capi.status_string(int(st[0]))))
+        return Path([RealVectorState(row) for row in self._batch.path(0)])
+
+    def is_state_valid(self, state):
+        """the checker's predicate, evaluated on the device (the reference calls the user's callable)"""
+        return bool(self._batch.is_valid(np.array([state.values]))[0])
+
+    @property
+    def num_nodes(self):
+        return int(self._batch.counts()["nodes"][0])

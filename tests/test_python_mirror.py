@@ -1,0 +1,105 @@
+"""The oxmpl_py class-surface mirror (oxmpl_amd.base / oxmpl_amd.geometric).
+
+test_rrt_finds_path_in_rvss is the reference's oxmpl-py/tests/test_rrt_rvss.py with the import line
+changed and the per-state Python callback replaced by its obstacle description."""
+import math
+import random
+
+import pytest
+
+from oxmpl_amd.base import RealVectorState, RealVectorStateSpace, ProblemDefinition, SphereBoxValidityChecker, Path
+from oxmpl_amd.geometric import RRT
+
+
+class CircularGoal:
+    def __init__(self, space, x, y, radius):
+        self.space = space
+        self.target = RealVectorState([x, y])
+        self.radius = radius
+        self.rng = random.Random(123)
+
+    def is_satisfied(self, state):
+        return self.space.distance(self.target, state) <= self.radius
+
+    def sample_goal(self):
+        angle = self.rng.uniform(0, 2 * math.pi)
+        radius = self.radius * math.sqrt(self.rng.uniform(0, 1))
+        return RealVectorState([self.target.values[0] + radius * math.cos(angle),
+                                self.target.values[1] + radius * math.sin(angle)])
+
+
+def is_state_valid(state):
+    x, y = state.values
+    return not (4.75 <= x <= 5.25 and 2.0 <= y <= 8.0)
+
+
+def test_constructors_and_errors_match_the_reference():
+    s = RealVectorStateSpace(dimension=2, bounds=[(-1.0, 1.0), (-2.0, 2.0)])
+    assert s.dimension == 2 and s.longest_valid_segment_fraction == 0.05
+    u = RealVectorStateSpace(3)
+    assert u.bounds[0] == (-math.inf, math.inf)  # real_vector_state_space.rs:61-63
+    with pytest.raises(ValueError, match="does not match specified dimension"):
+        RealVectorStateSpace(3, [(0.0, 1.0)])
+    with pytest.raises(ValueError, match="is greater than upper bound"):
+        RealVectorStateSpace(1, [(1.0, 1.0)])
+    with pytest.raises(ValueError, match="0-dimensional"):
+        RealVectorStateSpace(0)
+    s.set_longest_valid_segment_fraction(7.0)
+    assert s.longest_valid_segment_fraction == 1.0
+    s.set_longest_valid_segment_fraction(-1.0)
+    assert s.longest_valid_segment_fraction == 0.0
+    st = RealVectorState([1, 2])
+    assert st.values == [1.0, 2.0] and "RealVectorState" in repr(st)
+    assert len(Path.from_real_vector_states([st, st])) == 2
+    goal = CircularGoal(s, 0.5, 0.5, 0.1)
+    pd = ProblemDefinition.from_real_vector(s, st, goal)
+    with pytest.raises(TypeError):
+        ProblemDefinition.from_real_vector(s, st, object())
+    planner = RRT(max_distance=0.5, goal_bias=0.05, problem_definition=pd)
+    with pytest.raises(Exception, match="not set up"):
+        planner.solve(timeout_secs=1.0)          # PlanningError::PlannerUninitialised
+    with pytest.raises(TypeError, match="Python function per interpolated state"):
+        planner.setup(is_state_valid)             # closures are refused, never run on a CPU path
+
+
+@pytest.mark.gpu
+def test_rrt_finds_path_in_rvss():
+    space = RealVectorStateSpace(dimension=2, bounds=[(0.0, 10.0), (0.0, 10.0)])
+    start_state = RealVectorState([1.0, 5.0])
+    goal_region = CircularGoal(space, x=9.0, y=5.0, radius=0.5)
+    problem_def = ProblemDefinition.from_real_vector(space, start_state, goal_region)
+    planner = RRT(max_distance=0.5, goal_bias=0.05, problem_definition=problem_def)
+    planner.setup(SphereBoxValidityChecker(boxes=[([4.75, 2.0], [5.25, 8.0])]))
+    try:
+        path = planner.solve(timeout_secs=5.0)
+    except Exception as e:  # noqa: BLE001 - the reference test does the same
+        pytest.fail(f"Planner failed to find a solution when one should exist. Error: {e}")
+    assert len(path.states) > 1, "Path should contain at least a start and end state."
+    assert space.distance(path.states[0], start_state) < 1e-9, "Path must start at the start state."
+    assert goal_region.is_satisfied(path.states[-1]), "Path must end inside the goal region."
+    for state in path.states:
+        assert is_state_valid(state), f"Path contains an invalid state: {state.values}"
+        assert planner.is_state_valid(state)
+    assert abs(space.get_maximum_extent() - math.sqrt(200.0)) < 1e-12
+
+
+@pytest.mark.gpu
+def test_readme_quickstart_python():
+    """README.md:138-181 (config 1): disc obstacle r=2 at the origin, start (-5,-5), goal (5,5) r=0.5"""
+    space = RealVectorStateSpace(dimension=2, bounds=[(-10.0, 10.0), (-10.0, 10.0)])
+    goal = CircularGoal(space, 5.0, 5.0, 0.5)
+    pd = ProblemDefinition.from_real_vector(space, RealVectorState([-5.0, -5.0]), goal)
+    planner = RRT(max_distance=0.5, goal_bias=0.05, problem_definition=pd)
+    planner.setup(SphereBoxValidityChecker(spheres=[([0.0, 0.0], 2.0)]))
+    path = planner.solve(timeout_secs=5.0)
+    assert len(path.states) > 1
+    for s in path.states:
+        x, y = s.values
+        assert math.sqrt(x ** 2 + y ** 2) > 2.0
+    assert goal.is_satisfied(path.states[-1])
+    # an unreachable goal times out with the reference's message
+    far = CircularGoal(space, 0.0, 0.0, 0.5)  # inside the obstacle
+    p2 = RRT(0.5, 0.0, ProblemDefinition.from_real_vector(space, RealVectorState([-5.0, -5.0]), far), max_nodes=200)
+    p2.setup(SphereBoxValidityChecker(spheres=[([0.0, 0.0], 2.0)]))
+    with pytest.raises(Exception, match="No solution found|timed out"):
+        p2.solve(timeout_secs=0.2)
