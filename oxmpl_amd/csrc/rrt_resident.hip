@@ -1,24 +1,18 @@
-// rrt_resident.hip -- register-resident RRT grow kernel for gfx950.
+// rrt_resident.hip -- register-resident RRT grow kernel for gfx950 (the fast path).
 //
-// One 1024-thread workgroup (16 wave64 = the whole register file of one CU) per problem.
-// Thread t keeps tree nodes {t + 1024*s : s < S} in its VGPRs (S*DIM f64 = 60 VGPRs for
-// R^3, 10,240 nodes), so the O(n) nearest-neighbour scan of rrt.rs:187-196 reads no memory
-// at all: it is bounded by f64 VALU issue, not by HBM.  The SoA tree in HBM is only the
-// persistent copy (written once per insert, read once at launch).
-//
-// Per iteration: every wave scans its 640 nodes (d2 compare, no sqrt), reduces with DPP,
-// publishes (d2, index, candidate coordinates) to LDS; after one barrier every wave derives
-// the same nearest node, steers, and the 16 waves split the motion check's interpolated
-// states (one state per wave, one obstacle per lane); a second barrier ORs the verdicts.
+// A 10,240-node R^3 tree is 240 KB: too big for LDS (160 KB) but it fits the 512 KB vector
+// register file of one CU.  One 576-thread workgroup per problem: 8 scanner waves hold the tree in
+// VGPRs (126 VGPRs for R^3) and stream queries from an LDS ring, so the O(n) nearest-neighbour scan
+// of rrt.rs:187-196 reads no memory at all and is bounded by f64 VALU issue; one resolver wave
+// samples ahead, consumes the scanners' candidates in order, steers, checks the motion and commits.
+// No workgroup barrier in steady state (see "Asynchronous pipeline" below).  The SoA tree in HBM
+// is only the persistent copy: written once per insert, read once per launch.
 //
 // Replaces the loop body of RRT::solve, oxmpl/src/geometric/planners/rrt.rs:170-225.
 #include "oxhip_internal.hpp"
 #include "rrt_device.hpp"
 
 namespace oxhip {
-
-constexpr int kResThreads = 1024;
-constexpr int kResWaves = kResThreads / 64;
 
 // ---- wave64 min of an f64 with DPP (VALU only, no LDS crossbar); result is wave-uniform
 template <int CTRL, int ROW_MASK>
