@@ -171,7 +171,8 @@ struct PipeShared {
     QSlot<DIM> qring[kRing];
     WavePub<DIM> pub[kRing][kScanWaves];
     uint32_t done[kRing];                // scanner waves that have published this slot
-    double newn[64][DIM];                // the last 64 committed nodes, node i at i & 63
+    double newn[64][DIM];                // the last 64 committed nodes, node i at i & 63 (+inf for skipped duplicates)
+    double obs[DIM + 1][64];             // first 64 spheres for the row-parallel filter: centre, filter threshold
     uint32_t sampled;                    // queries sampled so far   (monotonic)
     uint32_t resolved;                   // queries resolved so far  (monotonic)
     uint32_t committed;                  // tree size                (monotonic)
@@ -209,16 +210,12 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// steer (rrt.rs:199-208) + check_motion (rrt.rs:90-116) in the resolver wave, one obstacle per
-// lane (registers).  A conservative midpoint filter settles most motions with one distance per
-// sphere: every interpolated state lies within max_distance/2 of the segment midpoint, so
-// d2(centre, mid) > (r + max_distance/2 + margin)^2 proves the sphere cannot be hit.  Only if a
-// sphere fails the filter are the interpolated states tested, exactly as the reference does; the
-// verdict is identical either way (the filter only skips provably valid work).
+// steer (rrt.rs:199-208): q_new = q when within max_distance of q_near, else the point at max_distance.
+// `have_dist`: g_or_dist is the post-sqrt distance (exact path); otherwise it is d2 and the test
+// sqrt(d2) > max_distance is the exact threshold compare d2 > t_steer.
 template <int DIM>
-__device__ __forceinline__ bool steer_and_check(const DevParams& p, uint32_t lane, bool have_dist, double g_or_dist,
-                                                const double q_near[DIM], const double q[DIM], const double oc[DIM],
-                                                double othr, double ofilt, uint32_t ns64, double q_new[DIM]) {
+__device__ __forceinline__ void steer(const DevParams& p, bool have_dist, double g_or_dist, const double q_near[DIM],
+                                      const double q[DIM], double q_new[DIM]) {
     const bool far = have_dist ? (g_or_dist > p.max_distance) : (g_or_dist > p.t_steer);
     if (far) {
         const double md = have_dist ? g_or_dist : sqrt(g_or_dist);
@@ -228,13 +225,14 @@ __device__ __forceinline__ bool steer_and_check(const DevParams& p, uint32_t lan
 #pragma unroll
         for (int k = 0; k < DIM; ++k) q_new[k] = q[k];
     }
+}
+
+// check_motion (rrt.rs:90-116) by the whole resolver wave: one obstacle per lane (registers), the
+// interpolated states in sequence, stopping at the first invalid one like the reference.
+template <int DIM>
+__device__ __forceinline__ bool motion_full(const DevParams& p, uint32_t lane, const double q_near[DIM], const double q_new[DIM],
+                                            const double oc[DIM], double othr, uint32_t ns64) {
     const uint32_t nobs = p.n_spheres + p.n_boxes;
-    if (nobs == 0) return true;
-    double mid[DIM];
-    lerp<DIM>(q_near, q_new, 0.5, mid, DIM);
-    const bool maybe = !(dist2<DIM>(oc, mid, DIM) > ofilt);
-    const bool extras = nobs > ns64;  // spheres beyond the first 64 and every box: always stepped
-    if (__ballot(maybe) == 0 && !extras) return true;
     const double dist = sqrt(dist2<DIM>(q_near, q_new, DIM));
     const uint32_t nsteps = num_steps_u32(dist, p.res);
     bool bad = false;
@@ -250,10 +248,34 @@ __device__ __forceinline__ bool steer_and_check(const DevParams& p, uint32_t lan
             lerp<DIM>(q_near, q_new, t, x, DIM);
             bad = bad || !(dist2<DIM>(oc, x, DIM) > othr);
             for (uint32_t j = ns64 + lane; j < nobs; j += 64) bad = bad || obstacle_hit<DIM>(p, DIM, x, j);
-            if (__ballot(bad) != 0) break;  // the reference also stops at the first invalid state
+            if (__ballot(bad) != 0) break;
         }
     }
     return __ballot(bad) == 0;
+}
+
+// Conservative midpoint filter (exactness: DESIGN.md section 3): every interpolated state lies within
+// max_distance/2 of the segment midpoint, so d2(centre, mid) > (r + max_distance/2 + margin)^2 proves
+// a sphere cannot be hit.  The filter never decides a motion invalid; it only skips provably valid work.
+template <int DIM>
+__device__ __forceinline__ bool sphere_maybe_hit(const double c[DIM], double filt, const double mid[DIM]) {
+    return !(dist2<DIM>(c, mid, DIM) > filt);
+}
+
+// min over each 16-lane DPP row (every lane ends up with its row's minimum)
+__device__ __forceinline__ double row_min_f64(double v) {
+    v = dpp_min_step<0xB1, 0xf>(v);
+    v = dpp_min_step<0x4E, 0xf>(v);
+    v = dpp_min_step<0x141, 0xf>(v);
+    v = dpp_min_step<0x140, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {
+    v = dpp_umin_step<0xB1, 0xf>(v);
+    v = dpp_umin_step<0x4E, 0xf>(v);
+    v = dpp_umin_step<0x141, 0xf>(v);
+    v = dpp_umin_step<0x140, 0xf>(v);
+    return v;
 }
 
 // Lane-parallel sampling of m <= 64 consecutive queries (rrt.rs:177-184 + rvss.rs:233-249): lane l
@@ -470,28 +492,103 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
 #pragma unroll
     for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
     const double goal_thr = p.goal_thr[prob];
+    const uint32_t nobs = p.n_spheres + p.n_boxes;
     const uint32_t ns64 = p.n_spheres < 64 ? p.n_spheres : 64;
-    // this lane's obstacle (unused lanes hold a sphere that can never be hit)
+    const bool extras = nobs > ns64;  // spheres beyond the first 64 and every box: always stepped, never filtered
+    // this lane's obstacle (unused lanes hold a sphere that can never be hit), also mirrored to LDS
     double oc[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) oc[k] = lane < ns64 ? p.sph_c[(size_t)k * p.n_spheres + lane] : 0.0;
     const double othr = lane < ns64 ? p.sph_thr[lane] : -1.0;
     const double ofilt = lane < ns64 ? p.sph_filt[lane] : -1.0;
-    // this lane's recent node: the last committed node i with (i & 63) == lane
-    double pn[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) pn[k] = 0.0;
-    uint32_t pidx = kNoNode;
+    for (int k = 0; k < D; ++k) sh.obs[k][lane] = oc[k];
+    sh.obs[D][lane] = ofilt;
 
     RngWindow rng;
     rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
     uint64_t draws_done = st.draws;
     uint32_t n = st.n_nodes;
-    uint32_t js = 0;
+    uint32_t js = 0, jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
+    const uint32_t row = lane >> 4, sub = lane & 15;
     uint64_t t_wait = 0, t_work = 0, t_samp = 0, t_comb = 0, n_amb = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
 
-    for (uint32_t jr = 0; jr < budget; ++jr) {
+    // ---- one query, the reference's sequential semantics in full (tails, batch conflicts, near-ties):
+    //      candidates = the 8 scanner waves' + every node committed after the oldest scan snapshot
+    auto resolve_one = [&](uint32_t jq, uint32_t& nearest, double (&q_new)[D], bool& dup) -> bool {
+        const uint32_t slot = jq & (kRing - 1);
+        double q[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) q[k] = unid(sh.qring[slot].q[k]);
+        const bool inS = lane < (uint32_t)kScanWaves;
+        const WavePub<DIM>& mine = sh.pub[slot][inS ? lane : 0];
+        const double pb = inS ? mine.b1 : __builtin_inf();
+        const uint32_t pan = inS ? mine.amb_nc : 0xFFFFFFFFu;
+        const uint32_t pamb = inS ? (pan & 1u) : 0u;
+        const uint32_t pidxS = inS ? mine.i1 : kNoNode;
+        const uint32_t base_min = wave_min_u32(pan >> 1);  // oldest snapshot among the 8 scans
+        // the ring entry of this lane holds the latest node i with (i & 63) == lane
+        uint32_t pidx = kNoNode;
+        if (n > lane) {
+            const uint32_t i = lane + (((n - 1u - lane) >> 6) << 6);
+            if (i >= base_min) pidx = i;
+        }
+        double pn[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) pn[k] = sh.newn[lane][k];
+        const bool pv = pidx != kNoNode;
+        const double d2p = pv ? dist2<D>(pn, q, DIM) : __builtin_inf();
+        const double g = wave_min_f64(d2p < pb ? d2p : pb);
+        const uint32_t hb = hi32(g) + 1;
+        const bool nearS = inS && hi32(pb) <= hb;
+        const bool nearP = pv && hi32(d2p) <= hb;
+        const uint64_t mS = __ballot(nearS), mP = __ballot(nearP);
+        const bool from_scan = mS != 0;
+        const int wl = from_scan ? (__ffsll((unsigned long long)mS) - 1) : (mP ? (__ffsll((unsigned long long)mP) - 1) : 0);
+        nearest = from_scan ? (uint32_t)__builtin_amdgcn_readlane((int)pidxS, wl)
+                            : (uint32_t)__builtin_amdgcn_readlane((int)pidx, wl);
+        // unambiguous iff every near candidate is that one node and no near wave saw a second near node
+        const bool amb = __ballot((nearS && (pidxS != nearest || pamb != 0)) || (nearP && pidx != nearest)) != 0;
+        double q_near[D];
+        double dist_or_g;
+        if (!amb) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) q_near[k] = from_scan ? unid(sh.pub[slot][wl].c[k]) : unid(sh.newn[wl][k]);
+            dist_or_g = g;
+            dup = g == 0.0;
+        } else {
+            // rare (~1e-6 of queries): the reference's own loop -- post-sqrt compare with lowest-index ties --
+            // over the persistent copy of the tree in global memory
+            if (STAMP) ++n_amb;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            Exact e{__builtin_inf(), kNoNode};
+            for (uint32_t i = lane; i < n; i += 64) {
+                double c[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+                    c[k] = __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double d = sqrt(dist2<D>(c, q, DIM));
+                if (d < e.dist) { e.dist = d; e.idx = i; }
+            }
+            e = exact_wave_reduce(e);
+            nearest = uni(e.idx);
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                q_near[k] = unid(__hip_atomic_load(&tree[(size_t)k * cap + nearest], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            dist_or_g = unid(e.dist);
+            dup = dist_or_g == 0.0;
+        }
+        steer<DIM>(p, amb, dist_or_g, q_near, q, q_new);
+        if (nobs == 0) return true;
+        double mid[D];
+        lerp<DIM>(q_near, q_new, 0.5, mid, DIM);
+        if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid)) == 0 && !extras) return true;
+        return motion_full<DIM>(p, lane, q_near, q_new, oc, othr, ns64);
+    };
+
+    while (jr < budget) {
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
         // sample ahead (rrt.rs:177-184); a query may only reuse a ring slot after its previous tenant was resolved
         if (js < budget && js - jr <= (uint32_t)(kRing / 2)) {
@@ -522,114 +619,167 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
             if (lane == 0) lds_post(&sh.sampled, js);
         }
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_samp += now - t_mark; t_mark = now; }
-        const uint32_t slot = jr & (kRing - 1);
+
+        // the scanners publish kBatch queries per pass: resolve them as one batch
+        const uint32_t nbq = (budget - jr < (uint32_t)kBatch) ? (budget - jr) : (uint32_t)kBatch;
         uint32_t spins = 0;
-        while (uni(lds_peek(&sh.done[slot])) < (uint32_t)kScanWaves && spins <= kMaxSpins) {
-            __builtin_amdgcn_s_sleep(1);
-            ++spins;
+        for (uint32_t b = 0; b < nbq; ++b) {
+            while (uni(lds_peek(&sh.done[(jr + b) & (kRing - 1)])) < (uint32_t)kScanWaves && spins <= kMaxSpins) {
+                __builtin_amdgcn_s_sleep(1);
+                ++spins;
+            }
         }
         if (spins > kMaxSpins) { stop = 4; break; }  // OXHIP_STOP_INTERNAL: a scanner never published (bug guard)
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_wait += now - t_mark; t_mark = now; }
 
+        // ---- row-parallel phase: DPP row r (16 lanes) works on query jr + r against the tree of n0 nodes
+        const uint32_t n0 = n;
+        const bool active = row < nbq;
+        const uint32_t slot_r = (jr + (active ? row : 0u)) & (kRing - 1);
         double q[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) q[k] = unid(sh.qring[slot].q[k]);
-        // candidates: one per scanner wave (lanes 0..7) + the recent nodes the scans did not cover (all lanes)
-        const bool inS = lane < (uint32_t)kScanWaves;
-        const WavePub<DIM>& mine = sh.pub[slot][inS ? lane : 0];
+        for (int k = 0; k < D; ++k) q[k] = sh.qring[slot_r].q[k];
+        const uint64_t pos_after_r = sh.qring[slot_r].pos_after;
+        const bool inS = active && sub < (uint32_t)kScanWaves;
+        const WavePub<DIM>& mine = sh.pub[slot_r][inS ? sub : 0];
         const double pb = inS ? mine.b1 : __builtin_inf();
         const uint32_t pan = inS ? mine.amb_nc : 0xFFFFFFFFu;
-        const uint32_t pamb = inS ? (pan & 1u) : 0u;
         const uint32_t pidxS = inS ? mine.i1 : kNoNode;
-        const uint32_t base_min = wave_min_u32(pan >> 1);  // oldest snapshot among the 8 scans
-        const bool pv = pidx != kNoNode && pidx >= base_min;
-        const double d2p = pv ? dist2<D>(pn, q, DIM) : __builtin_inf();
-        const double g = wave_min_f64(d2p < pb ? d2p : pb);  // one reduction over both candidate kinds
-        const uint32_t hb = hi32(g) + 1;
-        const bool nearS = inS && hi32(pb) <= hb;
-        const bool nearP = pv && hi32(d2p) <= hb;
-        const uint64_t mS = __ballot(nearS), mP = __ballot(nearP);
-        const bool from_scan = mS != 0;
-        const int wl = from_scan ? (__ffsll((unsigned long long)mS) - 1) : (mP ? (__ffsll((unsigned long long)mP) - 1) : 0);
-        uint32_t nearest = from_scan ? (uint32_t)__builtin_amdgcn_readlane((int)pidxS, wl)
-                                     : (uint32_t)__builtin_amdgcn_readlane((int)pidx, wl);
-        // unambiguous iff every near candidate is that one node and no near wave saw a second near node
-        const bool amb = __ballot((nearS && (pidxS != nearest || pamb != 0)) || (nearP && pidx != nearest)) != 0;
-
-        if (STAMP) { uint64_t now = (uint64_t)clock64(); t_comb += now - t_mark; t_mark = now; if (amb) ++n_amb; }
-        double q_near[D], q_new[D];
-        bool ok;
-        bool dup;  // q coincides with its nearest node: an accepted q_new is then a coordinate duplicate of it
-        if (!amb) {
-            dup = g == 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) q_near[k] = from_scan ? unid(sh.pub[slot][wl].c[k]) : readlane_f64(pn[k], wl);
-            ok = steer_and_check<DIM>(p, lane, false, g, q_near, q, oc, othr, ofilt, ns64, q_new);
-        } else {
-            // rare (~1e-6 of queries, or exact duplicates): the reference's own loop -- post-sqrt compare with
-            // lowest-index ties -- over the persistent copy of the tree in global memory
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            Exact e{__builtin_inf(), kNoNode};
-            for (uint32_t i = lane; i < n; i += 64) {
+        const uint32_t bmin_r = row_min_u32(pan >> 1);  // oldest scan snapshot for this row's query
+        if (__ballot(active && (n0 - bmin_r > 64u || bmin_r > n0)) != 0) { stop = 4; break; }  // ring would have wrapped (bug guard)
+        // nodes committed after that snapshot (at most a few): lanes of the row stride over them
+        Scan pd{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
+        if (active) {
+            for (uint32_t i = bmin_r + sub; i < n0; i += 16) {
                 double c[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k)
-                    c[k] = __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double d = sqrt(dist2<D>(c, q, DIM));
-                if (d < e.dist) { e.dist = d; e.idx = i; }
+                for (int k = 0; k < D; ++k) c[k] = sh.newn[i & 63][k];
+                scan_push(pd, dist2<D>(c, q, DIM), i);  // ascending i: ties keep the lower index
             }
-            e = exact_wave_reduce(e);
-            nearest = uni(e.idx);
-#pragma unroll
-            for (int k = 0; k < D; ++k)
-                q_near[k] = unid(__hip_atomic_load(&tree[(size_t)k * cap + nearest], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            ok = steer_and_check<DIM>(p, lane, true, unid(e.dist), q_near, q, oc, othr, ofilt, ns64, q_new);
-            dup = unid(e.dist) == 0.0;
         }
+        const double g_r = row_min_f64(pd.b1 < pb ? pd.b1 : pb);
+        const uint32_t hb = hi32(g_r) + 1;
+        const bool nearS = inS && hi32(pb) <= hb;
+        const bool nearP = active && pd.slot != kNoNode && hi32(pd.b1) <= hb;
+        const uint32_t rowS = (uint32_t)(__ballot(nearS) >> (16 * row)) & 0xFFFFu;
+        const uint32_t rowP = (uint32_t)(__ballot(nearP) >> (16 * row)) & 0xFFFFu;
+        const bool from_scan = rowS != 0;
+        const uint32_t wsub = from_scan ? (uint32_t)(__ffs((int)rowS) - 1) : (rowP ? (uint32_t)(__ffs((int)rowP) - 1) : 0u);
+        const int src_lane = (int)(16 * row + wsub);
+        const uint32_t wS = (uint32_t)__shfl((int)pidxS, src_lane, 64), wP = (uint32_t)__shfl((int)pd.slot, src_lane, 64);
+        const uint32_t nearest_r = from_scan ? wS : wP;
+        // ambiguous iff a second node is near: another near candidate, a near wave that saw a second near node,
+        // or a lane whose second-best recent node is near too
+        const bool amb_l = (nearS && (pidxS != nearest_r || (pan & 1u) != 0)) || (nearP && pd.slot != nearest_r) ||
+                           (active && pd.h2 <= hb);
+        const bool amb_r = ((uint32_t)(__ballot(amb_l) >> (16 * row)) & 0xFFFFu) != 0 || (rowS == 0 && rowP == 0);
+        double q_near[D], qn[D], mid[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) q_near[k] = from_scan ? sh.pub[slot_r][wsub].c[k] : sh.newn[nearest_r & 63][k];
+        steer<DIM>(p, false, g_r, q_near, q, qn);
+        lerp<DIM>(q_near, qn, 0.5, mid, DIM);
+        bool maybe_l = false;
+        if (nobs > 0) {
+            for (uint32_t o = sub; o < 64; o += 16) {
+                double c[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) c[k] = sh.obs[k][o];
+                maybe_l = maybe_l || sphere_maybe_hit<DIM>(c, sh.obs[D][o], mid);
+            }
+        }
+        const bool maybe_r = extras || (((uint32_t)(__ballot(maybe_l) >> (16 * row)) & 0xFFFFu) != 0);
+        if (STAMP) { uint64_t now = (uint64_t)clock64(); t_comb += now - t_mark; t_mark = now; }
 
-        // bookkeeping (wave-uniform, on the scalar unit where the compiler can)
-        uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
+        // ---- sequential phase: commit in query order; a node committed earlier in this batch that is
+        //      closer (or near-tied) to a later query forces that query through resolve_one
+        double cn[kBatch][D];   // coordinates the scanners will hold for the nodes committed in this batch
+        bool cn_valid[kBatch];
 #pragma unroll
-        for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(q_new[k])));
-        st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
-        st.iterations++;
-        draws_done = sh.qring[slot].pos_after;
-        bool hit = false;
-        if (ok) {
-            st.accepted++;
-            if (!p.freeze) {
-                // 6. insert (rrt.rs:213-217): recent-node lane, LDS hand-off to the owning scanner lane, HBM copy
-                const uint32_t i = n;
-                // A node at distance 0 from its nearest node repeats that node's coordinates, and the strict '<'
-                // of rrt.rs:192 can never prefer it over the lower index: the scanners keep +inf for it.
-                if (lane == (i & 63)) {
-                    pidx = i;
+        for (int b = 0; b < kBatch; ++b) cn_valid[b] = false;
+        bool leave = false;
+        uint32_t processed = 0;
 #pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double live = dup ? __builtin_inf() : q_new[k];
-                        pn[k] = live;
-                        sh.newn[i & 63][k] = live;
-                        tree[(size_t)k * cap + i] = q_new[k];
+        for (int b = 0; b < kBatch; ++b) {
+            if (!leave && (uint32_t)b < nbq) {
+                if (!p.freeze && n >= p.max_nodes) { stop = 2; leave = true; }
+            }
+            if (!leave && (uint32_t)b < nbq) {
+                const int l0 = 16 * b;
+                const uint32_t slot = (jr + (uint32_t)b) & (kRing - 1);
+                const double g_b = readlane_f64(g_r, l0);
+                double q_b[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) q_b[k] = readlane_f64(q[k], l0);
+                bool redo = __builtin_amdgcn_readlane(amb_r ? 1 : 0, l0) != 0;
+#pragma unroll
+                for (int c = 0; c < b; ++c)
+                    if (cn_valid[c] && hi32(dist2<D>(cn[c], q_b, DIM)) <= hi32(g_b) + 1) redo = true;
+                uint32_t nearest;
+                double q_new[D];
+                bool ok, dup;
+                if (redo) {
+                    ok = resolve_one(jr + (uint32_t)b, nearest, q_new, dup);
+                } else {
+                    nearest = (uint32_t)__builtin_amdgcn_readlane((int)nearest_r, l0);
+#pragma unroll
+                    for (int k = 0; k < D; ++k) q_new[k] = readlane_f64(qn[k], l0);
+                    dup = g_b == 0.0;
+                    ok = true;
+                    if (nobs > 0 && __builtin_amdgcn_readlane(maybe_r ? 1 : 0, l0) != 0) {
+                        double qnr[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) qnr[k] = readlane_f64(q_near[k], l0);
+                        ok = motion_full<DIM>(p, lane, qnr, q_new, oc, othr, ns64);
                     }
-                    parent[i] = (int32_t)nearest;
-                    skip[i] = dup ? 1 : 0;
                 }
-                ++n;
-                if (lane == 0) lds_post(&sh.committed, n);
-                // 7. goal test (rrt.rs:220-223)
-                if (dist2<D>(q_new, goal_c, DIM) <= goal_thr) {
-                    if (st.goal_node < 0) st.goal_node = (int32_t)i;
-                    hit = true;
+                // bookkeeping (wave-uniform, on the scalar unit where the compiler can)
+                uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
+#pragma unroll
+                for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(q_new[k])));
+                st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
+                st.iterations++;
+                draws_done = uni64((uint64_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_r, l0) |
+                                   ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_r >> 32), l0) << 32));
+                bool hit = false;
+                if (ok) {
+                    st.accepted++;
+                    if (!p.freeze) {
+                        // 6. insert (rrt.rs:213-217): LDS hand-off to the owning scanner lane + HBM copy.  A node at
+                        // distance 0 from its nearest node repeats that node's coordinates, and the strict '<' of
+                        // rrt.rs:192 can never prefer it over the lower index: the scanners keep +inf for it.
+                        const uint32_t i = n;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) cn[b][k] = dup ? __builtin_inf() : q_new[k];
+                        cn_valid[b] = true;
+                        if (lane == (i & 63)) {
+#pragma unroll
+                            for (int k = 0; k < D; ++k) {
+                                sh.newn[i & 63][k] = cn[b][k];
+                                tree[(size_t)k * cap + i] = q_new[k];
+                            }
+                            parent[i] = (int32_t)nearest;
+                            skip[i] = dup ? 1 : 0;
+                        }
+                        ++n;
+                        if (lane == 0) lds_post(&sh.committed, n);
+                        // 7. goal test (rrt.rs:220-223)
+                        if (dist2<D>(q_new, goal_c, DIM) <= goal_thr) {
+                            if (st.goal_node < 0) st.goal_node = (int32_t)i;
+                            hit = true;
+                        }
+                    }
                 }
+                if (lane == 0) {
+                    lds_post(&sh.done[slot], 0);                 // free the slot ...
+                    lds_post(&sh.resolved, jr + (uint32_t)b + 1); // ... before the sampler may hand it out again
+                }
+                ++processed;
+                if (hit && p.stop_at_goal) { stop = 0; leave = true; }
             }
         }
-        if (lane == 0) {
-            lds_post(&sh.done[slot], 0);          // free the slot ...
-            lds_post(&sh.resolved, jr + 1);       // ... before the sampler may hand it out again
-        }
+        jr += processed;
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
-        if (hit && p.stop_at_goal) { stop = 0; break; }
+        if (leave) break;
     }
     if (lane == 0) {
         lds_post(&sh.stop_flag, 1);
