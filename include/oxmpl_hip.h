@@ -55,6 +55,11 @@ typedef enum oxhip_stop_reason {
     OXHIP_STOP_INTERNAL = 4     /* kernel-internal hand-off never completed (bug guard); solve returns OXHIP_ERR_HIP */
 } oxhip_stop_reason;
 
+typedef enum oxhip_planner_kind {
+    OXHIP_PLANNER_RRT = 0,         /* geometric::RRT         oxmpl/src/geometric/planners/rrt.rs */
+    OXHIP_PLANNER_RRT_CONNECT = 1  /* geometric::RRTConnect  oxmpl/src/geometric/planners/rrt_connect.rs (stream kernel only) */
+} oxhip_planner_kind;
+
 typedef enum oxhip_kernel_kind {
     OXHIP_KERNEL_AUTO = 0,      /* resident when the tree fits the register file, else streaming */
     OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
@@ -78,7 +83,7 @@ typedef struct oxhip_rrt_config {
     uint64_t seed;                      /* RNG key: ChaCha12 key = LE(seed)||0^24, stream id = first_problem_id + p */
     uint64_t first_problem_id;          /* global id of problem 0 of this batch (problem-parallel sharding) */
     int32_t  device;                    /* HIP device ordinal */
-    uint32_t reserved;
+    uint32_t planner;                   /* oxhip_planner_kind: 0 = RRT (rrt.rs), 1 = RRTConnect (rrt_connect.rs) */
 } oxhip_rrt_config;
 
 typedef struct oxhip_rrt_batch oxhip_rrt_batch;
@@ -141,6 +146,14 @@ int32_t oxhip_rrt_batch_get_tree(oxhip_rrt_batch* b, uint32_t problem, double* s
 /* reconstruct_path (rrt.rs:118-128) from the first goal node; len = 0 when unsolved. */
 int32_t oxhip_rrt_batch_get_path(oxhip_rrt_batch* b, uint32_t problem, double* states,
                                  uint32_t cap_states, uint32_t* len);
+
+/* RRTConnect only (rrt_connect.rs:58-59: start_tree / goal_tree).  get_tree / get_counts above address the
+ * start tree (nodes[], goal_node[] = last start-tree node of the solution); these address the goal tree:
+ * its size, the last goal-tree node of the solution (-1 when the start tree reached the goal itself,
+ * rrt_connect.rs:271-274) and its nodes.  get_path returns the merged path of rrt_connect.rs:288-304. */
+int32_t oxhip_rrt_batch_get_goal_counts(oxhip_rrt_batch* b, uint32_t* nodes /*[P]*/, int32_t* end_node /*[P]*/);
+int32_t oxhip_rrt_batch_get_goal_tree(oxhip_rrt_batch* b, uint32_t problem, double* states, int32_t* parents,
+                                      uint32_t cap_nodes, uint32_t* n_nodes);
 
 /* HIP-event time (ms) of the kernels of the last solve call, their launch count, and which
  * kernel ran (oxhip_kernel_kind). */

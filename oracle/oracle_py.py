@@ -80,6 +80,26 @@ def lib():
         L.orc_rrt_is_valid.argtypes = [C.c_void_p, _dp]
         L.orc_nearest.argtypes = [_dp, C.c_uint32, C.c_uint32, _dp, _dp]
         L.orc_nearest.restype = C.c_uint32
+        L.orc_rrtc_new.argtypes = [C.c_uint32, _dp, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint64, C.c_uint64,
+                                   C.POINTER(C.c_int)]
+        L.orc_rrtc_new.restype = C.c_void_p
+        L.orc_rrtc_free.argtypes = [C.c_void_p]
+        L.orc_rrtc_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.orc_rrtc_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.orc_rrtc_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.orc_rrtc_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
+        L.orc_rrtc_num_nodes.argtypes = [C.c_void_p, C.c_int]
+        L.orc_rrtc_num_nodes.restype = C.c_uint32
+        for name in ("orc_rrtc_iterations", "orc_rrtc_checksum"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint64
+        L.orc_rrtc_end_node.argtypes = [C.c_void_p, C.c_int]
+        L.orc_rrtc_end_node.restype = C.c_int32
+        L.orc_rrtc_stop_reason.argtypes = [C.c_void_p]
+        L.orc_rrtc_stop_reason.restype = C.c_int32
+        L.orc_rrtc_get_tree.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int32)]
+        L.orc_rrtc_get_path.argtypes = [C.c_void_p, _dp, C.c_uint32]
+        L.orc_rrtc_get_path.restype = C.c_uint32
         L.orc_rrt_solve_many.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, C.c_int,
                                          C.c_uint32]
         _lib = L
@@ -234,6 +254,64 @@ class OracleRRT:
     def is_valid(self, p):
         p, pp = _d(p)
         return bool(lib().orc_rrt_is_valid(self.h, pp))
+
+
+class OracleRRTConnect:
+    """oxmpl RRTConnect<RealVectorState, RealVectorStateSpace, BallGoal> (rrt_connect.rs)"""
+
+    def __init__(self, dim, bounds, max_distance, goal_bias, lvs_fraction=0.05, max_nodes=10000, seed=0, problem_id=0):
+        self.dim = dim
+        b, pb = _d(np.asarray(bounds, dtype=np.float64).reshape(-1))
+        st = C.c_int()
+        self.h = lib().orc_rrtc_new(dim, pb, max_distance, goal_bias, lvs_fraction, max_nodes, seed, problem_id, C.byref(st))
+        if not self.h:
+            raise ValueError("orc_rrtc_new failed with status %d" % st.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_rrtc_free(self.h)
+            self.h = None
+
+    def set_spheres(self, centres, radii):
+        c, pc = _d(np.asarray(centres, dtype=np.float64).reshape(-1, self.dim))
+        r, pr = _d(radii)
+        lib().orc_rrtc_set_spheres(self.h, pc, pr, r.size)
+
+    def set_boxes(self, lo, hi):
+        l, pl = _d(np.asarray(lo, dtype=np.float64).reshape(-1, self.dim))
+        h, ph = _d(np.asarray(hi, dtype=np.float64).reshape(-1, self.dim))
+        lib().orc_rrtc_set_boxes(self.h, pl, ph, l.shape[0])
+
+    def setup(self, start, goal_centre, goal_radius):
+        s, ps = _d(start)
+        g, pg = _d(goal_centre)
+        return lib().orc_rrtc_setup(self.h, ps, pg, goal_radius)
+
+    def solve(self, max_iterations, timeout_s=float("inf")):
+        return lib().orc_rrtc_solve(self.h, max_iterations, timeout_s)
+
+    def num_nodes(self, which):
+        return lib().orc_rrtc_num_nodes(self.h, which)
+
+    iterations = property(lambda self: lib().orc_rrtc_iterations(self.h))
+    checksum = property(lambda self: lib().orc_rrtc_checksum(self.h))
+    stop_reason = property(lambda self: lib().orc_rrtc_stop_reason(self.h))
+
+    def end_node(self, which):
+        return lib().orc_rrtc_end_node(self.h, which)
+
+    def tree(self, which):
+        n = self.num_nodes(which)
+        states = np.empty((n, self.dim), dtype=np.float64)
+        parents = np.empty(n, dtype=np.int32)
+        lib().orc_rrtc_get_tree(self.h, which, states.ctypes.data_as(_dp), parents.ctypes.data_as(C.POINTER(C.c_int32)))
+        return states, parents
+
+    def path(self):
+        cap = self.num_nodes(0) + self.num_nodes(1)
+        out = np.empty((cap, self.dim), dtype=np.float64)
+        ln = lib().orc_rrtc_get_path(self.h, out.ctypes.data_as(_dp), cap)
+        return out[:ln].copy()
 
 
 def solve_many(planners, max_iterations, freeze=False, threads=1):

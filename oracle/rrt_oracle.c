@@ -488,6 +488,183 @@ uint32_t orc_nearest(const double* nodes, uint32_t n, uint32_t dim, const double
 }
 
 /* ------------------------------------------------------------------------- */
+/* RRTConnect: rrt_connect.rs:86-309                                          */
+/* ------------------------------------------------------------------------- */
+
+struct orc_rrtc {
+    orc_rrt* a;          /* start tree + everything shared (space, checker, rng, goal) */
+    orc_node* tree_b;    /* goal tree */
+    uint32_t nb, capb;
+    int32_t end_a, end_b;
+};
+
+orc_rrtc* orc_rrtc_new(uint32_t dim, const double* bounds, double max_distance, double goal_bias, double lvs_fraction,
+                       uint32_t max_nodes, uint64_t seed, uint64_t problem_id, int* status) {
+    orc_rrt* a = orc_rrt_new(dim, bounds, max_distance, goal_bias, lvs_fraction, max_nodes, 1, seed, problem_id, status);
+    if (!a) return NULL;
+    orc_rrtc* r = (orc_rrtc*)calloc(1, sizeof *r);
+    r->a = a;
+    r->end_a = r->end_b = -1;
+    return r;
+}
+
+static void rrtc_clear_b(orc_rrtc* r) {
+    for (uint32_t i = 0; i < r->nb; ++i) free(r->tree_b[i].values);
+    r->nb = 0;
+}
+
+void orc_rrtc_free(orc_rrtc* r) {
+    if (!r) return;
+    rrtc_clear_b(r);
+    free(r->tree_b);
+    orc_rrt_free(r->a);
+    free(r);
+}
+
+int orc_rrtc_set_spheres(orc_rrtc* r, const double* c, const double* rad, uint32_t n) { return orc_rrt_set_spheres(r->a, c, rad, n); }
+int orc_rrtc_set_boxes(orc_rrtc* r, const double* lo, const double* hi, uint32_t n) { return orc_rrt_set_boxes(r->a, lo, hi, n); }
+
+static void push_b(orc_rrtc* r, const double* state, int64_t parent) {
+    if (r->nb == r->capb) {
+        r->capb = r->capb ? r->capb * 2 : 4;
+        r->tree_b = (orc_node*)realloc(r->tree_b, sizeof(orc_node) * r->capb);
+    }
+    r->tree_b[r->nb].values = dup_vec(state, r->a->dim);
+    r->tree_b[r->nb].parent = parent;
+    r->nb++;
+}
+
+/* rrt_connect.rs:199-225: start tree = [start]; goal tree = [goal.sample_goal()] (the ball goal's sampler
+ * returns its centre and draws nothing) */
+int orc_rrtc_setup(orc_rrtc* r, const double* start, const double* goal_centre, double goal_radius) {
+    orc_rrt_setup(r->a, start, goal_centre, goal_radius);
+    rrtc_clear_b(r);
+    push_b(r, goal_centre, -1);
+    r->end_a = r->end_b = -1;
+    return ORC_SOLVED;
+}
+
+/* rrt_connect.rs:121-159.  `tree`/`n` select the tree; returns 0 = motion invalid (None),
+ * 1 = Advanced, 2 = Reached; *nearest_out and q_new are always filled (for the checksum). */
+static int rrtc_extend(orc_rrtc* r, int which, const double* q_target, uint32_t* nearest_out, double* q_new) {
+    orc_rrt* a = r->a;
+    const uint32_t dim = a->dim;
+    orc_node* tree = which ? r->tree_b : a->tree;
+    const uint32_t n = which ? r->nb : a->n;
+    uint32_t nearest = 0;
+    double min_dist = orc_distance(tree[0].values, q_target, dim);
+    for (uint32_t i = 1; i < n; ++i) {
+        double d = orc_distance(tree[i].values, q_target, dim);
+        if (d < min_dist) { min_dist = d; nearest = i; }
+    }
+    double* q_near = dup_vec(tree[nearest].values, dim); /* q_near.clone() */
+    int result;
+    if (min_dist > a->max_distance) {
+        double t = a->max_distance / min_dist;
+        orc_interpolate(q_near, q_target, t, q_new, dim);
+        result = 1;
+    } else {
+        memcpy(q_new, q_target, sizeof(double) * dim);
+        result = 2;
+    }
+    *nearest_out = nearest;
+    int ok = check_motion(a, q_near, q_new);
+    free(q_near);
+    if (!ok) return 0;
+    if (which) push_b(r, q_new, (int64_t)nearest);
+    else push_node(a, q_new, (int64_t)nearest);
+    return result;
+}
+
+/* rrt_connect.rs:227-309 with the same build-defined termination as orc_rrt_solve: an iteration budget
+ * and a node cap (either tree full, checked before any draw of the iteration). */
+int orc_rrtc_solve(orc_rrtc* r, uint64_t max_iterations, double timeout_s) {
+    orc_rrt* a = r->a;
+    if (!a->is_setup) return ORC_PLANNER_UNINITIALISED;
+    if (r->end_a >= 0) return ORC_SOLVED;
+    const uint32_t dim = a->dim;
+    double start_time = now_s();
+    a->stop_reason = ORC_STOP_ITERATIONS;
+    double* q_rand = (double*)malloc(sizeof(double) * dim);
+    double* q_new_a = (double*)malloc(sizeof(double) * dim);
+    double* q_new_b = (double*)malloc(sizeof(double) * dim);
+    int status = ORC_NO_SOLUTION_FOUND;
+    for (uint64_t it = 0; it < max_iterations; ++it) {
+        if (now_s() - start_time > timeout_s) { a->stop_reason = ORC_STOP_TIMEOUT; status = ORC_TIMEOUT; break; }
+        if (a->n >= a->max_nodes || r->nb >= a->max_nodes) { a->stop_reason = ORC_STOP_NODES; break; }
+        const int grow_start = a->n <= r->nb; /* rrt_connect.rs:249-254 */
+        if (orc_random_bool(&a->rng, a->goal_bias)) memcpy(q_rand, a->goal_centre, sizeof(double) * dim);
+        else
+            for (uint32_t k = 0; k < dim; ++k) q_rand[k] = orc_random_range(&a->rng, a->bounds[2 * k], a->bounds[2 * k + 1]);
+        uint32_t near_a = 0, near_b = 0;
+        const int ra = rrtc_extend(r, grow_start ? 0 : 1, q_rand, &near_a, q_new_a);
+        uint64_t h = fnv_mix(a->checksum, (uint64_t)grow_start);
+        h = fnv_mix(h, (uint64_t)near_a);
+        for (uint32_t k = 0; k < dim; ++k) { uint64_t b; memcpy(&b, &q_new_a[k], 8); h = fnv_mix(h, b); }
+        h = fnv_mix(h, (uint64_t)ra);
+        a->iterations++;
+        int done = 0;
+        if (ra) {
+            const uint32_t idx_a = (grow_start ? a->n : r->nb) - 1;
+            if (grow_start && goal_is_satisfied(a, q_new_a)) { /* rrt_connect.rs:271-274 */
+                r->end_a = (int32_t)idx_a;
+                r->end_b = -1;
+                done = 1;
+            } else {
+                const int rb = rrtc_extend(r, grow_start ? 1 : 0, q_new_a, &near_b, q_new_b);
+                h = fnv_mix(h, (uint64_t)near_b);
+                for (uint32_t k = 0; k < dim; ++k) { uint64_t b; memcpy(&b, &q_new_b[k], 8); h = fnv_mix(h, b); }
+                h = fnv_mix(h, (uint64_t)rb);
+                if (rb == 2) { /* Reached: rrt_connect.rs:281-305 */
+                    const uint32_t idx_b = (grow_start ? r->nb : a->n) - 1;
+                    r->end_a = (int32_t)(grow_start ? idx_a : idx_b);
+                    r->end_b = (int32_t)(grow_start ? idx_b : idx_a);
+                    done = 1;
+                }
+            }
+        }
+        a->checksum = h;
+        if (done) { a->stop_reason = ORC_STOP_GOAL; status = ORC_SOLVED; break; }
+    }
+    free(q_rand); free(q_new_a); free(q_new_b);
+    return status;
+}
+
+uint32_t orc_rrtc_num_nodes(const orc_rrtc* r, int which) { return which ? r->nb : r->a->n; }
+uint64_t orc_rrtc_iterations(const orc_rrtc* r) { return r->a->iterations; }
+uint64_t orc_rrtc_checksum(const orc_rrtc* r) { return r->a->checksum; }
+int32_t orc_rrtc_end_node(const orc_rrtc* r, int which) { return which ? r->end_b : r->end_a; }
+int32_t orc_rrtc_stop_reason(const orc_rrtc* r) { return r->a->stop_reason; }
+
+void orc_rrtc_get_tree(const orc_rrtc* r, int which, double* states, int32_t* parents) {
+    const orc_node* tree = which ? r->tree_b : r->a->tree;
+    const uint32_t n = which ? r->nb : r->a->n, dim = r->a->dim;
+    for (uint32_t i = 0; i < n; ++i) {
+        memcpy(states + (size_t)i * dim, tree[i].values, sizeof(double) * dim);
+        parents[i] = (int32_t)tree[i].parent;
+    }
+}
+
+/* rrt_connect.rs:288-304: start-tree chain root..end_a, then the goal-tree chain from end_b's parent
+ * side reversed (goal path reversed, first element -- the duplicate connection point -- skipped) */
+uint32_t orc_rrtc_get_path(const orc_rrtc* r, double* out, uint32_t cap) {
+    if (r->end_a < 0) return 0;
+    const uint32_t dim = r->a->dim;
+    uint32_t la = 0, lb = 0;
+    for (int64_t i = r->end_a; i >= 0; i = r->a->tree[i].parent) ++la;
+    if (r->end_b >= 0) for (int64_t i = r->end_b; i >= 0; i = r->tree_b[i].parent) ++lb;
+    const uint32_t len = la + (lb ? lb - 1 : 0);
+    if (len > cap) return len;
+    uint32_t pos = la;
+    for (int64_t i = r->end_a; i >= 0; i = r->a->tree[i].parent) { --pos; memcpy(out + (size_t)pos * dim, r->a->tree[i].values, sizeof(double) * dim); }
+    /* reconstruct_path(goal_tree, end_b) = [goal root .. end_b]; reversed = [end_b .. root]; skip(1) drops end_b */
+    pos = la;
+    if (r->end_b >= 0)
+        for (int64_t i = r->tree_b[r->end_b].parent; i >= 0; i = r->tree_b[i].parent) { memcpy(out + (size_t)pos * dim, r->tree_b[i].values, sizeof(double) * dim); ++pos; }
+    return len;
+}
+
+/* ------------------------------------------------------------------------- */
 /* problem-parallel driver for the CPU baseline (one planner per problem,    */
 /* the reference itself is single-threaded per planner)                      */
 /* ------------------------------------------------------------------------- */

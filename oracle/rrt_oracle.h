@@ -101,6 +101,25 @@ int orc_rrt_is_valid(const orc_rrt* r, const double* p);
 /* nearest neighbour exactly as rrt.rs:187-196 over an AoS array */
 uint32_t orc_nearest(const double* nodes_aos, uint32_t n, uint32_t dim, const double* q, double* min_dist);
 
+/* ---- RRTConnect (oxmpl/src/geometric/planners/rrt_connect.rs:86-309) ----
+ * Same construction arguments as orc_rrt_new (max_nodes caps EACH tree).  Returns the status;
+ * counters / trees through the getters; which = 0 start tree, 1 goal tree. */
+typedef struct orc_rrtc orc_rrtc;
+orc_rrtc* orc_rrtc_new(uint32_t dim, const double* bounds, double max_distance, double goal_bias, double lvs_fraction,
+                       uint32_t max_nodes, uint64_t seed, uint64_t problem_id, int* status);
+void orc_rrtc_free(orc_rrtc* r);
+int orc_rrtc_set_spheres(orc_rrtc* r, const double* centres, const double* radii, uint32_t n);
+int orc_rrtc_set_boxes(orc_rrtc* r, const double* lo, const double* hi, uint32_t n);
+int orc_rrtc_setup(orc_rrtc* r, const double* start, const double* goal_centre, double goal_radius);
+int orc_rrtc_solve(orc_rrtc* r, uint64_t max_iterations, double timeout_s);
+uint32_t orc_rrtc_num_nodes(const orc_rrtc* r, int which);
+uint64_t orc_rrtc_iterations(const orc_rrtc* r);
+uint64_t orc_rrtc_checksum(const orc_rrtc* r);
+int32_t orc_rrtc_end_node(const orc_rrtc* r, int which);   /* last node of the solution in each tree, -1 = none */
+int32_t orc_rrtc_stop_reason(const orc_rrtc* r);
+void orc_rrtc_get_tree(const orc_rrtc* r, int which, double* states, int32_t* parents);
+uint32_t orc_rrtc_get_path(const orc_rrtc* r, double* out, uint32_t cap);
+
 /* run many independent problems on `threads` host threads (cpu_baseline leg) */
 int orc_rrt_solve_many(orc_rrt** planners, uint32_t n, uint64_t max_iterations, int freeze,
                        uint32_t threads);

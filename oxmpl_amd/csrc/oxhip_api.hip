@@ -119,7 +119,9 @@ struct oxhip_rrt_batch {
     DevBuf<double> tree, goal_c, goal_thr, sph_c, sph_thr, sph_filt, box_lo, box_hi;
     std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
     bool filt_dirty = true;
+    DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<int32_t> parent;
+    DevBuf<int32_t> parent_b;
     DevBuf<uint8_t> skip;
     DevBuf<ProblemState> state;
     DevBuf<uint64_t> dbg;
@@ -175,6 +177,9 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (!(cfg->max_distance > 0.0) || !std::isfinite(cfg->max_distance))
         return fail(OXHIP_ERR_BAD_ARG, "max_distance must be finite and > 0");
     if (cfg->kernel > OXHIP_KERNEL_RESIDENT) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
+    if (cfg->planner > OXHIP_PLANNER_RRT_CONNECT) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
+    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel == OXHIP_KERNEL_RESIDENT)
+        return fail(OXHIP_ERR_BAD_ARG, "RRTConnect runs on the stream kernel only");
     for (uint32_t k = 0; k < cfg->dim; ++k) {
         double lo = cfg->bounds[2 * k], hi = cfg->bounds[2 * k + 1];
         if (!std::isfinite(lo) || !std::isfinite(hi))  // real_vector_state_space.rs:239-241
@@ -230,6 +235,10 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     chk(b->tree.alloc((size_t)P * dim * cap));
     chk(b->parent.alloc((size_t)P * cap));
     chk(b->skip.alloc((size_t)P * cap));
+    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT) {
+        chk(b->tree_b.alloc((size_t)P * dim * cap));
+        chk(b->parent_b.alloc((size_t)P * cap));
+    }
     chk(b->state.alloc(P));
     chk(b->goal_c.alloc((size_t)P * dim));
     chk(b->goal_thr.alloc(P));
@@ -239,9 +248,11 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_HIP, msg);
     }
     dp.tree = b->tree.p; dp.parent = b->parent.p; dp.skip = b->skip.p; dp.state = b->state.p;
+    dp.tree_b = b->tree_b.p; dp.parent_b = b->parent_b.p;
     dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p;
 
     uint32_t kind = cfg->kernel;
+    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT) kind = OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO) kind = resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_RESIDENT && !resident_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
@@ -331,6 +342,8 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
         s.checksum = kFnvBasis;
         s.n_nodes = 1;
         s.goal_node = -1;
+        s.goal_node_b = -1;
+        s.n_nodes_b = b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT ? 1 : 0;
         s.stop_reason = OXHIP_STOP_NONE;
     }
     std::vector<int32_t> root(1, -1);
@@ -345,6 +358,13 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
     std::vector<int32_t> minus1(P, -1);
     HIP_TRY(hipMemcpy2DAsync(b->parent.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
                              sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
+    if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) {
+        // goal_tree.push(Node{goal.sample_goal(), None})  rrt_connect.rs:218-224 (the ball goal samples its centre)
+        HIP_TRY(hipMemcpy2DAsync(b->tree_b.p, (size_t)cap * sizeof(double), goal_centres, sizeof(double), sizeof(double),
+                                 (size_t)P * dim, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpy2DAsync(b->parent_b.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
+                                 sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
+    }
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->is_setup = true;
     return OXHIP_OK;
@@ -385,6 +405,7 @@ int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const dou
     if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");
     if (problem >= b->cfg.n_problems) return fail(OXHIP_ERR_BAD_ARG, "problem index out of range");
     if (n == 0 || n > b->cfg.max_nodes) return fail(OXHIP_ERR_BAD_ARG, "n_nodes must be in 1..max_nodes");
+    if (b->cfg.planner != OXHIP_PLANNER_RRT) return fail(OXHIP_ERR_BAD_ARG, "set_tree is for the RRT planner");
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
     const uint32_t dim = b->cfg.dim, cap = b->dp.cap;
@@ -443,6 +464,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
     if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");  // rrt.rs:160-163
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
+    if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT && freeze) return fail(OXHIP_ERR_BAD_ARG, "freeze is for the RRT planner");
     if ((st = refresh_filter(b)) != OXHIP_OK) return st;
     const bool has_timeout = timeout_s > 0.0 && std::isfinite(timeout_s);
     const auto t0 = std::chrono::steady_clock::now();
@@ -459,7 +481,8 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         b->dp.budget = step;
         b->dp.freeze = freeze ? 1 : 0;
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
-        if (b->kernel_kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
+        if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
+        else if (b->kernel_kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
         else launch_rrt_stream(b->dp, b->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -516,14 +539,16 @@ int32_t oxhip_rrt_batch_get_counts(oxhip_rrt_batch* b, uint64_t* iterations, uin
 }
 
 static int32_t fetch_tree(oxhip_rrt_batch* b, uint32_t problem, uint32_t n, std::vector<double>& soa,
-                          std::vector<int32_t>& parents) {
+                          std::vector<int32_t>& parents, bool goal_tree = false) {
     const uint32_t dim = b->cfg.dim, cap = b->dp.cap;
+    const double* tree_base = goal_tree ? b->tree_b.p : b->tree.p;
+    const int32_t* parent_base = goal_tree ? b->parent_b.p : b->parent.p;
     soa.resize((size_t)dim * n);
     parents.resize(n);
     // [dim][n] out of [dim][cap]
-    HIP_TRY(hipMemcpy2DAsync(soa.data(), (size_t)n * sizeof(double), b->tree.p + (size_t)problem * dim * cap,
+    HIP_TRY(hipMemcpy2DAsync(soa.data(), (size_t)n * sizeof(double), tree_base + (size_t)problem * dim * cap,
                              (size_t)cap * sizeof(double), (size_t)n * sizeof(double), dim, hipMemcpyDeviceToHost, b->stream));
-    HIP_TRY(hipMemcpyAsync(parents.data(), b->parent.p + (size_t)problem * cap, (size_t)n * sizeof(int32_t),
+    HIP_TRY(hipMemcpyAsync(parents.data(), parent_base + (size_t)problem * cap, (size_t)n * sizeof(int32_t),
                            hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return OXHIP_OK;
@@ -573,12 +598,66 @@ int32_t oxhip_rrt_batch_get_path(oxhip_rrt_batch* b, uint32_t problem, double* s
         chain.push_back((uint32_t)i);
         if (chain.size() > n) return fail(OXHIP_ERR_HIP, "parent chain is cyclic (corrupt tree)");
     }
-    *len = (uint32_t)chain.size();
-    if (chain.size() > cap_states || !states_out) return chain.size() > cap_states ? fail(OXHIP_ERR_CAPACITY, "path buffer too small") : OXHIP_OK;
+    // RRTConnect (rrt_connect.rs:288-304): append the goal-tree chain from the connection node's parent to
+    // the goal root (the reversed goal path with its first element, the duplicate connection point, skipped)
+    std::vector<double> soa_b;
+    std::vector<int32_t> par_b;
+    std::vector<uint32_t> chain_b;
+    const uint32_t nb = states[problem].n_nodes_b;
+    if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT && states[problem].goal_node_b >= 0) {
+        if ((st = fetch_tree(b, problem, nb, soa_b, par_b, true)) != OXHIP_OK) return st;
+        for (int64_t i = par_b[(size_t)states[problem].goal_node_b]; i >= 0; i = par_b[(size_t)i]) {
+            chain_b.push_back((uint32_t)i);
+            if (chain_b.size() > nb) return fail(OXHIP_ERR_HIP, "goal-tree parent chain is cyclic (corrupt tree)");
+        }
+    }
+    const size_t total = chain.size() + chain_b.size();
+    *len = (uint32_t)total;
+    if (total > cap_states || !states_out) return total > cap_states ? fail(OXHIP_ERR_CAPACITY, "path buffer too small") : OXHIP_OK;
     for (size_t j = 0; j < chain.size(); ++j) {
         uint32_t i = chain[chain.size() - 1 - j];
         for (uint32_t k = 0; k < dim; ++k) states_out[j * dim + k] = soa[(size_t)k * n + i];
     }
+    for (size_t j = 0; j < chain_b.size(); ++j)
+        for (uint32_t k = 0; k < dim; ++k) states_out[(chain.size() + j) * dim + k] = soa_b[(size_t)k * nb + chain_b[j]];
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_get_goal_counts(oxhip_rrt_batch* b, uint32_t* nodes, int32_t* end_node) {
+    if (!b) return fail(OXHIP_ERR_BAD_ARG, "null batch");
+    if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");
+    if (b->cfg.planner != OXHIP_PLANNER_RRT_CONNECT) return fail(OXHIP_ERR_BAD_ARG, "not an RRTConnect batch");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    std::vector<ProblemState> states;
+    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    for (uint32_t p = 0; p < b->cfg.n_problems; ++p) {
+        if (nodes) nodes[p] = states[p].n_nodes_b;
+        if (end_node) end_node[p] = states[p].goal_node_b;
+    }
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_get_goal_tree(oxhip_rrt_batch* b, uint32_t problem, double* states_out, int32_t* parents_out,
+                                      uint32_t cap_nodes, uint32_t* n_nodes) {
+    if (!b || !n_nodes) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");
+    if (b->cfg.planner != OXHIP_PLANNER_RRT_CONNECT) return fail(OXHIP_ERR_BAD_ARG, "not an RRTConnect batch");
+    if (problem >= b->cfg.n_problems) return fail(OXHIP_ERR_BAD_ARG, "problem index out of range");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    std::vector<ProblemState> states;
+    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    const uint32_t n = states[problem].n_nodes_b, dim = b->cfg.dim;
+    *n_nodes = n;
+    if (n > cap_nodes || (!states_out && !parents_out)) return n > cap_nodes ? fail(OXHIP_ERR_CAPACITY, "tree buffer too small") : OXHIP_OK;
+    std::vector<double> soa;
+    std::vector<int32_t> par;
+    if ((st = fetch_tree(b, problem, n, soa, par, true)) != OXHIP_OK) return st;
+    if (states_out)
+        for (uint32_t i = 0; i < n; ++i)
+            for (uint32_t k = 0; k < dim; ++k) states_out[(size_t)i * dim + k] = soa[(size_t)k * n + i];
+    if (parents_out) std::memcpy(parents_out, par.data(), (size_t)n * sizeof(int32_t));
     return OXHIP_OK;
 }
 

@@ -1,0 +1,170 @@
+// rrt_connect.hip -- RRTConnect (oxmpl/src/geometric/planners/rrt_connect.rs:121-159,227-309) on the GPU:
+// one 256-thread workgroup per problem, both trees as SoA arrays in HBM / L2, every extend() a
+// coalesced nearest-neighbour scan + steer + striped motion check, exactly the primitives of
+// rrt_stream.hip.  Iteration k sees the trees left by iterations < k; per iteration up to two scans.
+#include "oxhip_internal.hpp"
+#include "rrt_device.hpp"
+
+namespace oxhip {
+
+constexpr int kConnThreads = 256;
+constexpr int kConnWaves = kConnThreads / 64;
+
+struct ConnShared {
+    uint32_t rng_buf[16][64];
+    Best wave_best[kConnWaves];
+    Exact wave_exact[kConnWaves];
+};
+
+// extend() of rrt_connect.rs:121-159 for the whole workgroup.  Returns 0 = motion invalid (None),
+// 1 = Advanced, 2 = Reached; `nearest` and `q_new` are filled in every case.  On success the new
+// node is appended at index n (thread 0 writes, a barrier makes it visible) and n is incremented.
+template <int D>
+__device__ __forceinline__ int wg_extend(const DevParams& p, int dim, ConnShared& sh, double* tree, int32_t* parent,
+                                         size_t cap, uint32_t& n, const double q[D], uint32_t& nearest, double q_new[D]) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // nearest node: d2 compare, second-smallest tracking, exact post-sqrt fallback (rrt_connect.rs:128-136)
+    Best best = best_init();
+    for (uint32_t i = tid; i < n; i += kConnThreads) {
+        double c[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree[(size_t)k * cap + i];
+        best_push(best, dist2<D>(c, q, dim), i);
+    }
+    best = best_wave_reduce(best);
+    if (lane == 0) sh.wave_best[wave] = best;
+    __syncthreads();
+    best = sh.wave_best[0];
+#pragma unroll
+    for (int w = 1; w < kConnWaves; ++w) best = best_combine(best, sh.wave_best[w]);
+    double min_dist;
+    if (best_ambiguous(best)) {
+        Exact e{__builtin_inf(), 0xFFFFFFFFu};
+        for (uint32_t i = tid; i < n; i += kConnThreads) {
+            double c[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree[(size_t)k * cap + i];
+            double d = sqrt(dist2<D>(c, q, dim));
+            if (d < e.dist) { e.dist = d; e.idx = i; }
+        }
+        e = exact_wave_reduce(e);
+        if (lane == 0) sh.wave_exact[wave] = e;
+        __syncthreads();
+        e = sh.wave_exact[0];
+#pragma unroll
+        for (int w = 1; w < kConnWaves; ++w) e = exact_combine(e, sh.wave_exact[w]);
+        nearest = e.idx;
+        min_dist = e.dist;
+    } else {
+        nearest = best.i1;
+        min_dist = sqrt(best.b1);
+    }
+    nearest = uni(nearest);
+    double q_near[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) if (k < dim) q_near[k] = tree[(size_t)k * cap + nearest];
+    int result;
+    if (min_dist > p.max_distance) {  // rrt_connect.rs:140-147
+        double t = p.max_distance / min_dist;
+        lerp<D>(q_near, q, t, q_new, dim);
+        result = 1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (k < dim) q_new[k] = q[k];
+        result = 2;
+    }
+    const bool bad = motion_invalid_partial<D>(p, dim, q_near, q_new, tid, kConnThreads);  // rrt_connect.rs:166-189
+    if (__syncthreads_or(bad ? 1 : 0)) return 0;
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (k < dim) tree[(size_t)k * cap + n] = q_new[k];
+        parent[n] = (int32_t)nearest;
+    }
+    ++n;
+    __syncthreads();
+    return result;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(kConnThreads) void rrt_connect_kernel(DevParams p) {
+    constexpr int D = DIM ? DIM : kMaxDim;
+    const int dim = DIM ? DIM : (int)p.dim;
+    const uint32_t prob = blockIdx.x, tid = threadIdx.x;
+    __shared__ ConnShared sh;
+
+    ProblemState st = p.state[prob];
+    if (st.goal_node >= 0) return;  // solved: RRTConnect::solve returned Ok
+
+    const size_t cap = p.cap;
+    double* tree_a = p.tree + (size_t)prob * p.dim * cap;
+    double* tree_b = p.tree_b + (size_t)prob * p.dim * cap;
+    int32_t* par_a = p.parent + (size_t)prob * cap;
+    int32_t* par_b = p.parent_b + (size_t)prob * cap;
+    double goal_c[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) if (k < dim) goal_c[k] = p.goal_c[(size_t)prob * p.dim + k];
+    const double goal_thr = p.goal_thr[prob];
+
+    RngWindow rng;
+    rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
+    uint32_t na = st.n_nodes, nb = st.n_nodes_b;
+    int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
+    for (uint64_t it = 0; it < p.budget; ++it) {
+        if (na >= p.max_nodes || nb >= p.max_nodes) { stop = 2; break; }
+        const bool grow_start = na <= nb;  // rrt_connect.rs:249-254
+        double q_rand[D];
+        sample_state<D>(rng, p, dim, goal_c, q_rand);  // rrt_connect.rs:258-262
+        uint32_t near_a = 0, near_b = 0;
+        double q_new_a[D], q_new_b[D];
+        const int ra = grow_start ? wg_extend<D>(p, dim, sh, tree_a, par_a, cap, na, q_rand, near_a, q_new_a)
+                                  : wg_extend<D>(p, dim, sh, tree_b, par_b, cap, nb, q_rand, near_a, q_new_a);
+        uint64_t h = fnv_mix(st.checksum, grow_start ? 1ull : 0ull);
+        h = fnv_mix(h, (uint64_t)near_a);
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (k < dim) h = fnv_mix(h, (uint64_t)__double_as_longlong(q_new_a[k]));
+        h = fnv_mix(h, (uint64_t)ra);
+        st.iterations++;
+        bool done = false;
+        if (ra) {
+            const uint32_t idx_a = (grow_start ? na : nb) - 1;
+            if (grow_start && dist2<D>(q_new_a, goal_c, dim) <= goal_thr) {  // rrt_connect.rs:271-274
+                st.goal_node = (int32_t)idx_a;
+                st.goal_node_b = -1;
+                done = true;
+            } else {
+                const int rb = grow_start ? wg_extend<D>(p, dim, sh, tree_b, par_b, cap, nb, q_new_a, near_b, q_new_b)
+                                          : wg_extend<D>(p, dim, sh, tree_a, par_a, cap, na, q_new_a, near_b, q_new_b);
+                h = fnv_mix(h, (uint64_t)near_b);
+#pragma unroll
+                for (int k = 0; k < D; ++k) if (k < dim) h = fnv_mix(h, (uint64_t)__double_as_longlong(q_new_b[k]));
+                h = fnv_mix(h, (uint64_t)rb);
+                if (rb == 2) {  // Reached: rrt_connect.rs:281-305
+                    const uint32_t idx_b = (grow_start ? nb : na) - 1;
+                    st.goal_node = (int32_t)(grow_start ? idx_a : idx_b);
+                    st.goal_node_b = (int32_t)(grow_start ? idx_b : idx_a);
+                    done = true;
+                }
+            }
+        }
+        st.checksum = h;
+        if (done) { stop = 0; break; }
+    }
+    if (tid == 0) {
+        st.n_nodes = na;
+        st.n_nodes_b = nb;
+        st.draws = rng.pos;
+        st.stop_reason = stop;
+        p.state[prob] = st;
+    }
+}
+
+void launch_rrt_connect(const DevParams& p, hipStream_t stream) {
+    dim3 grid(p.n_problems), block(kConnThreads);
+    switch (p.dim) {
+        case 2: hipLaunchKernelGGL(rrt_connect_kernel<2>, grid, block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(rrt_connect_kernel<3>, grid, block, 0, stream, p); break;
+        default: hipLaunchKernelGGL(rrt_connect_kernel<0>, grid, block, 0, stream, p); break;
+    }
+}
+
+}  // namespace oxhip

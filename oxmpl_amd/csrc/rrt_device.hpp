@@ -29,9 +29,11 @@ struct ProblemState {
     uint64_t accepted;
     uint64_t checksum;
     uint64_t draws;       // u64 words consumed from the problem's ChaCha12 stream
-    uint32_t n_nodes;
-    int32_t goal_node;    // first node satisfying the goal, -1 = none
+    uint32_t n_nodes;     // RRT: tree size; RRTConnect: start-tree size
+    int32_t goal_node;    // RRT: first node satisfying the goal; RRTConnect: last start-tree node of the solution; -1 = none
     int32_t stop_reason;  // oxhip_stop_reason of the last launch
+    uint32_t n_nodes_b;   // RRTConnect: goal-tree size
+    int32_t goal_node_b;  // RRTConnect: last goal-tree node of the solution (-1: the start tree reached the goal itself)
     uint32_t pad;
 };
 
@@ -52,6 +54,8 @@ struct DevParams {
     const double* box_hi;   // [dim][n_boxes]
     double* tree;           // [P][dim][cap]  SoA per problem
     int32_t* parent;        // [P][cap]
+    double* tree_b;         // RRTConnect goal trees, same layout (null for RRT)
+    int32_t* parent_b;
     uint8_t* skip;          // [P][cap] 1 = coordinate duplicate of a lower-index node: never nearest (resident kernel)
     ProblemState* state;    // [P]
     const double* goal_c;   // [P][dim]

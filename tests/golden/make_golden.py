@@ -242,6 +242,93 @@ def rrt_solve(dim, bounds, max_distance, goal_bias, fraction, field, start, goal
                 states=tree[:n].copy(), parents=parents, path=path, rng_draws=rng.draws)
 
 
+def _nearest(tree, n, q, dim):
+    acc = np.zeros(n)
+    for k in range(dim):
+        d = tree[:n, k] - q[k]
+        acc = acc + d * d
+    dists = np.sqrt(acc)
+    i = int(np.argmin(dists))
+    return i, float(dists[i])
+
+
+def rrt_connect_solve(dim, bounds, max_distance, goal_bias, fraction, field, start, goal_c, goal_r,
+                      seed, pid, max_iterations, max_nodes):
+    """oxmpl/src/geometric/planners/rrt_connect.rs:121-159,199-309 (goal tree root = goal centre)"""
+    rng = ChaCha12Rng(seed, pid)
+    trees = [np.zeros((max_nodes + 1, dim)), np.zeros((max_nodes + 1, dim))]
+    parents = [[-1], [-1]]
+    trees[0][0] = start
+    trees[1][0] = goal_c
+    n = [1, 1]
+    chk = 0xCBF29CE484222325
+    iterations = 0
+    end = [-1, -1]
+
+    def extend(w, target):
+        i, md = _nearest(trees[w], n[w], target, dim)
+        q_near = [float(v) for v in trees[w][i]]
+        if md > max_distance:
+            q_new, res = interpolate(q_near, target, max_distance / md), 1
+        else:
+            q_new, res = list(target), 2
+        if not check_motion(field, bounds, fraction, q_near, q_new):
+            return 0, i, q_new
+        trees[w][n[w]] = q_new
+        parents[w].append(i)
+        n[w] += 1
+        return res, i, q_new
+
+    for _ in range(max_iterations):
+        if n[0] >= max_nodes or n[1] >= max_nodes:
+            break
+        grow_start = n[0] <= n[1]
+        if random_bool(rng, goal_bias):
+            q_rand = list(goal_c)
+        else:
+            q_rand = [random_range(rng, lo, hi) for lo, hi in bounds]
+        wa, wb = (0, 1) if grow_start else (1, 0)
+        ra, near_a, q_new_a = extend(wa, q_rand)
+        chk = ((chk ^ int(grow_start)) * FNV_P) & M64
+        chk = ((chk ^ near_a) * FNV_P) & M64
+        for v in q_new_a:
+            chk = ((chk ^ f64_bits(v)) * FNV_P) & M64
+        chk = ((chk ^ ra) * FNV_P) & M64
+        iterations += 1
+        done = False
+        if ra:
+            idx_a = n[wa] - 1
+            if grow_start and distance(q_new_a, goal_c) <= goal_r:
+                end = [idx_a, -1]
+                done = True
+            else:
+                rb, near_b, q_new_b = extend(wb, q_new_a)
+                chk = ((chk ^ near_b) * FNV_P) & M64
+                for v in q_new_b:
+                    chk = ((chk ^ f64_bits(v)) * FNV_P) & M64
+                chk = ((chk ^ rb) * FNV_P) & M64
+                if rb == 2:
+                    idx_b = n[wb] - 1
+                    end = [idx_a, idx_b] if grow_start else [idx_b, idx_a]
+                    done = True
+        if done:
+            break
+    path = []
+    if end[0] >= 0:
+        i = end[0]
+        while i >= 0:
+            path.append([float(v) for v in trees[0][i]])
+            i = parents[0][i]
+        path.reverse()
+        if end[1] >= 0:
+            i = parents[1][end[1]]
+            while i >= 0:
+                path.append([float(v) for v in trees[1][i]])
+                i = parents[1][i]
+    return dict(n=n, iterations=iterations, checksum=chk, end=end, path=path, rng_draws=rng.draws,
+                states=[trees[0][:n[0]].copy(), trees[1][:n[1]].copy()], parents=parents)
+
+
 # --------------------------------------------------------------------- scenarios
 def splitmix64(state):
     state = (state + 0x9E3779B97F4A7C15) & M64
@@ -377,9 +464,26 @@ def main():
     # a frozen ("steady") leg on the tree grown above: 200 iterations, inserts suppressed
     out["config2"] = dict(params=c2, runs=runs)
 
+    # ---- RRTConnect (rrt_connect.rs) on the README scene and on the reference's wall test scene
+    #      (oxmpl/tests/rrt_connect_rvss_tests.rs: RRTConnect::new(0.5, 0.0))
+    for key, prm, fld in (("connect_config1", c1, f1), ("connect_wall", cw, fw)):
+        runs = []
+        for seed in range(4):
+            res = rrt_connect_solve(2, prm["bounds"], 0.5, prm["goal_bias"], 0.05, fld, prm["start"], prm["goal_c"], 0.5,
+                                    seed, 11, 200000, 20000)
+            runs.append(dict(seed=seed, pid=11, n=res["n"], iterations=res["iterations"], checksum="%016x" % res["checksum"],
+                             end=res["end"], rng_draws=res["rng_draws"],
+                             path=[[hexf(v) for v in row] for row in res["path"]],
+                             states=[[[hexf(v) for v in row] for row in t[:48]] for t in res["states"]],
+                             parents=[[int(x) for x in pp[:48]] for pp in res["parents"]]))
+        out[key] = dict(params=prm, runs=runs)
+
     with open(os.path.join(HERE, "rrt_golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "rrt_golden.json"))
+    for k in ("connect_config1", "connect_wall"):
+        for r in out[k]["runs"]:
+            print(k, "seed", r["seed"], "n", r["n"], "iters", r["iterations"], "end", r["end"], "path", len(r["path"]), "chk", r["checksum"])
     for k in ("config1", "wall", "config2"):
         for r in out[k]["runs"]:
             print(k, "seed", r["seed"], "pid", r["pid"], "n", r["n"], "iters", r["iterations"],

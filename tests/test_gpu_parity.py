@@ -490,3 +490,108 @@ def test_full_size_config2_properties(kernel):
         assert int(c["checksum"][p]) == pl.checksum and int(c["iterations"][p]) == pl.iterations
         assert int(c["accepted"][p]) == pl.accepted and int(c["nodes"][p]) == N
     gpu.close()
+
+
+# ------------------------------------------------------------------------------ RRTConnect
+def _oracle_connect(sc, seed, pid, max_nodes):
+    p = orc.OracleRRTConnect(sc["dim"], sc["bounds"], sc["max_distance"], sc["goal_bias"], sc["lvs_fraction"],
+                             max_nodes, seed, pid)
+    if sc["spheres"] is not None:
+        p.set_spheres(*sc["spheres"])
+    if sc["boxes"] is not None:
+        p.set_boxes(*sc["boxes"])
+    p.setup(sc["start"], sc["goal_centre"], sc["goal_radius"])
+    return p
+
+
+def _assert_same_connect(gpu, p, o, c, gc):
+    assert int(c["nodes"][p]) == o.num_nodes(0) and int(gc["nodes"][p]) == o.num_nodes(1)
+    assert int(c["iterations"][p]) == o.iterations and int(c["checksum"][p]) == o.checksum
+    assert int(c["goal_node"][p]) == o.end_node(0) and int(gc["end_node"][p]) == o.end_node(1)
+    for which, (gs, gp) in enumerate((gpu.tree(p), gpu.goal_tree(p))):
+        os_, op = o.tree(which)
+        assert np.array_equal(gp, op) and np.array_equal(bits(gs), bits(os_))
+    assert np.array_equal(bits(gpu.path(p)), bits(o.path()))
+
+
+@pytest.mark.parametrize("key", ["connect_config1", "connect_wall"])
+def test_rrt_connect_matches_golden_fixtures(golden, key):
+    """RRTConnect (rrt_connect.rs) on the README scene and on the reference's own test scene
+    (oxmpl/tests/rrt_connect_rvss_tests.rs, RRTConnect::new(0.5, 0.0)): both trees, merged path, checksum"""
+    params = golden[key]["params"]
+    sc = dict(dim=params["dim"], bounds=params["bounds"], max_distance=params["max_distance"],
+              goal_bias=params["goal_bias"], lvs_fraction=params["fraction"], start=params["start"],
+              goal_centre=params["goal_c"], goal_radius=params["goal_r"],
+              spheres=params_spheres(params) if params["spheres"] else None,
+              boxes=params_boxes(params) if params["boxes"] else None)
+    ov = _oracle_for(sc, 0, 0, 10, True)
+    for run in golden[key]["runs"]:
+        gpu = scenarios.make_batch(sc, 1, params["max_nodes"], True, run["seed"], run["pid"], 0, 0, capi.PLANNER_RRT_CONNECT)
+        st = gpu.solve(params["max_iterations"])
+        assert st[0] == capi.OK
+        c, gc = gpu.counts(), gpu.goal_counts()
+        assert [int(c["nodes"][0]), int(gc["nodes"][0])] == run["n"]
+        assert int(c["iterations"][0]) == run["iterations"] and "%016x" % int(c["checksum"][0]) == run["checksum"]
+        assert [int(c["goal_node"][0]), int(gc["end_node"][0])] == run["end"]
+        assert int(c["stop_reason"][0]) == capi.STOP_GOAL
+        for which, (states, parents) in enumerate((gpu.tree(0), gpu.goal_tree(0))):
+            m = len(run["parents"][which])
+            assert [[hexf(v) for v in row] for row in states[:m]] == run["states"][which]
+            assert list(parents[:m]) == run["parents"][which]
+        path = gpu.path(0)
+        assert [[hexf(v) for v in row] for row in path] == run["path"]
+        # the reference's assertions (rrt_connect_rvss_tests.rs:154-181)
+        assert len(path) > 0 and orc.distance(path[0], sc["start"]) < 1e-9
+        assert orc.distance(path[-1], sc["goal_centre"]) <= sc["goal_radius"]
+        assert is_path_valid(path, sc["bounds"], sc["lvs_fraction"], ov.is_valid, orc.maximum_extent,
+                             orc.num_steps, orc.interpolate, orc.distance)
+        it = int(c["iterations"][0])
+        gpu.solve(100)  # solved: a second solve is a no-op
+        assert int(gpu.counts()["iterations"][0]) == it
+        gpu.close()
+
+
+def test_rrt_connect_batch_matches_oracle():
+    """config 2 (R^3, 64 spheres), 64 problems: every problem equals the oracle; then caps, budgets, resume"""
+    sc = scenarios.config2()
+    P = 64
+    gpu = scenarios.make_batch(sc, P, 10000, True, 42, 500, 0, 0, capi.PLANNER_RRT_CONNECT)
+    st = gpu.solve(100000)
+    assert (st == capi.OK).all()
+    c, gc = gpu.counts(), gpu.goal_counts()
+    planners = [_oracle_connect(sc, 42, 500 + p, 10000) for p in range(P)]
+    for p, o in enumerate(planners):
+        assert o.solve(100000) == orc.SOLVED
+        _assert_same_connect(gpu, p, o, c, gc)
+    gpu.close()
+    # a 5-D problem with boxes + spheres on the runtime-dim kernel, goal_bias 0.3
+    rng = np.random.default_rng(4)
+    sc5 = dict(dim=5, bounds=[(-2.0, 6.0)] * 5, max_distance=0.9, goal_bias=0.3, lvs_fraction=0.03,
+               start=[-1.5] * 5, goal_centre=[5.5] * 5, goal_radius=0.3,
+               spheres=(rng.random((12, 5)) * 5.0, rng.random(12) * 0.6 + 0.2),
+               boxes=(np.array([[1.0] * 5]), np.array([[1.8] * 5])))
+    gpu = scenarios.make_batch(sc5, 6, 5000, True, 3, 0, 0, 0, capi.PLANNER_RRT_CONNECT)
+    gpu.solve(150)      # budget, then resume: 150 + 100000 == one long run
+    gpu.solve(100000)
+    c, gc = gpu.counts(), gpu.goal_counts()
+    for p in range(6):
+        o = _oracle_connect(sc5, 3, p, 5000)
+        o.solve(100150)
+        _assert_same_connect(gpu, p, o, c, gc)
+    gpu.close()
+    # node cap: a slab separates start from goal, both trees grow but can never connect
+    blocked = dict(sc)
+    blocked["spheres"] = None
+    blocked["boxes"] = (np.array([[4.5, -1.0, -1.0]]), np.array([[5.5, 11.0, 11.0]]))
+    gpu = scenarios.make_batch(blocked, 2, 300, True, 1, 0, 0, 0, capi.PLANNER_RRT_CONNECT)
+    st = gpu.solve(10 ** 6)
+    c, gc = gpu.counts(), gpu.goal_counts()
+    assert (st == capi.ERR_NO_SOLUTION_FOUND).all() and (c["stop_reason"] == capi.STOP_NODES).all()
+    assert ((c["nodes"] == 300) | (gc["nodes"] == 300)).all()
+    for p in range(2):
+        o = _oracle_connect(blocked, 1, p, 300)
+        assert o.solve(10 ** 6) == orc.NO_SOLUTION_FOUND
+        _assert_same_connect(gpu, p, o, c, gc)
+    with pytest.raises(capi.OxhipError):
+        gpu.solve(10, freeze=True)
+    gpu.close()

@@ -162,3 +162,40 @@ def test_oracle_nearest_ties_lowest_index():
     assert (i, d) == (0, 1.0)
     i, d = orc.nearest(np.array([[1.0, 0.0], [1.0, y]]), [0.0, 0.0])
     assert (i, d) == (0, 1.0)
+
+
+@pytest.mark.parametrize("key", ["connect_config1", "connect_wall"])
+def test_oracle_rrt_connect_matches_numpy_restatement(golden, key):
+    """RRTConnect (rrt_connect.rs:121-159,199-309): both trees, the merged path and the checksum"""
+    params = golden[key]["params"]
+    for run in golden[key]["runs"]:
+        p = orc.OracleRRTConnect(params["dim"], params["bounds"], params["max_distance"], params["goal_bias"],
+                                 params["fraction"], params["max_nodes"], run["seed"], run["pid"])
+        if params["spheres"]:
+            p.set_spheres(*params_spheres(params))
+        if params["boxes"]:
+            p.set_boxes(*params_boxes(params))
+        assert p.solve(10) == orc.PLANNER_UNINITIALISED
+        p.setup(params["start"], params["goal_c"], params["goal_r"])
+        assert p.solve(params["max_iterations"]) == orc.SOLVED
+        assert [p.num_nodes(0), p.num_nodes(1)] == run["n"]
+        assert p.iterations == run["iterations"] and "%016x" % p.checksum == run["checksum"]
+        assert [p.end_node(0), p.end_node(1)] == run["end"]
+        for w in (0, 1):
+            states, parents = p.tree(w)
+            m = len(run["parents"][w])
+            assert [[hexf(v) for v in row] for row in states[:m]] == run["states"][w]
+            assert list(parents[:m]) == run["parents"][w]
+        path = p.path()
+        assert [[hexf(v) for v in row] for row in path] == run["path"]
+        # the reference's assertions (oxmpl/tests/rrt_connect_rvss_tests.rs): start, goal, validity
+        o = orc.OracleRRT(params["dim"], params["bounds"], 0.5, 0.0, params["fraction"], 10, True, 0, 0)
+        if params["spheres"]:
+            o.set_spheres(*params_spheres(params))
+        if params["boxes"]:
+            o.set_boxes(*params_boxes(params))
+        assert orc.distance(path[0], params["start"]) < 1e-9
+        assert orc.distance(path[-1], params["goal_c"]) <= params["goal_r"]
+        assert is_path_valid(path, params["bounds"], params["fraction"], o.is_valid, orc.maximum_extent,
+                             orc.num_steps, orc.interpolate, orc.distance)
+        assert p.solve(100) == orc.SOLVED and p.iterations == run["iterations"]  # idempotent once solved
