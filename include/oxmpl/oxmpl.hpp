@@ -162,7 +162,7 @@ class RRT {
     int device = 0;
 
     RRT(double max_distance_, double goal_bias_) : max_distance(max_distance_), goal_bias(goal_bias_) {}  // rrt.rs:75-83
-    ~RRT() { reset(); }
+    virtual ~RRT() { reset(); }
     RRT(const RRT&) = delete;
     RRT& operator=(const RRT&) = delete;
 
@@ -191,6 +191,7 @@ class RRT {
         cfg.seed = seed;
         cfg.first_problem_id = problem_id;
         cfg.device = device;
+        cfg.planner = planner_kind();
         if ((last_status_ = oxhip_rrt_batch_create(&cfg, &batch_)) != OXHIP_OK) return;
         std::vector<double> c, r, lo, hi;
         for (auto& s : vc_->spheres()) { c.insert(c.end(), s.centre.begin(), s.centre.end()); r.push_back(s.radius); }
@@ -236,6 +237,9 @@ class RRT {
     }
     int32_t last_status() const { return last_status_; }
 
+  protected:
+    virtual uint32_t planner_kind() const { return OXHIP_PLANNER_RRT; }
+
   private:
     void reset() {
         if (batch_) (void)oxhip_rrt_batch_destroy(batch_);
@@ -245,6 +249,15 @@ class RRT {
     std::shared_ptr<base::ProblemDefinition> pd_;
     std::shared_ptr<base::StateValidityChecker> vc_;
     int32_t last_status_ = OXHIP_ERR_PLANNER_UNINITIALISED;
+};
+
+// RRTConnect (rrt_connect.rs:49-95): same Planner surface, two trees grown towards each other.
+class RRTConnect : public RRT {
+  public:
+    RRTConnect(double max_distance_, double goal_bias_) : RRT(max_distance_, goal_bias_) {}  // rrt_connect.rs:86-95
+
+  protected:
+    uint32_t planner_kind() const override { return OXHIP_PLANNER_RRT_CONNECT; }
 };
 
 }  // namespace geometric

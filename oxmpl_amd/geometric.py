@@ -20,6 +20,8 @@ _MESSAGES = {  # Display strings of PlanningError (oxmpl/src/base/error.rs:110-1
 
 
 class RRT:
+    _PLANNER = capi.PLANNER_RRT
+
     def __init__(self, max_distance, goal_bias, problem_definition, max_nodes=10000, seed=0, problem_id=0, device=0):
         if not isinstance(problem_definition, ProblemDefinition):
             raise TypeError("problem_definition must be a ProblemDefinition")
@@ -39,7 +41,8 @@ class RRT:
             self._batch.close()
         try:
             b = capi.RRTBatch(pd.space.dimension, pd.space.bounds, self.max_distance, self.goal_bias, 1,
-                              lvs_fraction=pd.space.longest_valid_segment_fraction, stop_at_goal=True, **self._opts)
+                              lvs_fraction=pd.space.longest_valid_segment_fraction, stop_at_goal=True,
+                              planner=self._PLANNER, **self._opts)
         except capi.OxhipError as e:
             if e.status in (capi.ERR_UNBOUNDED, capi.ERR_ZERO_VOLUME, capi.ERR_BAD_ARG):
                 raise ValueError(str(e)) from None
@@ -69,3 +72,14 @@ class RRT:
     @property
     def num_nodes(self):
         return int(self._batch.counts()["nodes"][0])
+
+
+class RRTConnect(RRT):
+    """oxmpl_py.geometric.RRTConnect (oxmpl-py/src/geometric/rrt_connect.rs; planner:
+    oxmpl/src/geometric/planners/rrt_connect.rs): same constructor / setup / solve surface as RRT,
+    two trees grown towards each other; `max_nodes` caps each tree."""
+    _PLANNER = capi.PLANNER_RRT_CONNECT
+
+    @property
+    def num_nodes(self):
+        return int(self._batch.counts()["nodes"][0]) + int(self._batch.goal_counts()["nodes"][0])

@@ -10,6 +10,7 @@
 
 using namespace oxmpl::base;
 using oxmpl::geometric::RRT;
+using oxmpl::geometric::RRTConnect;
 
 // rrt_rvss_tests.rs:17-36
 struct WallObstacleChecker : StateValidityChecker {
@@ -102,6 +103,17 @@ int main() {
     p2.setup(std::make_shared<ProblemDefinition>(ProblemDefinition{unb, {start_state}, goal_definition}), validity_checker);
     CHECK(p2.last_status() == OXHIP_ERR_UNBOUNDED, "unbounded space");
     CHECK(p2.solve(std::chrono::seconds(1)).err() == PlanningError::PlannerUninitialised, "unbounded solve");
+    // oxmpl/tests/rrt_connect_rvss_tests.rs: the same scene through RRTConnect::new(0.5, 0.0)
+    RRTConnect pc(0.5, 0.0);
+    pc.setup(problem_definition, validity_checker);
+    CHECK(pc.last_status() == OXHIP_OK, "RRTConnect setup");
+    auto rc = pc.solve(std::chrono::seconds(5));
+    CHECK(rc.is_ok(), "RRTConnect failed to find a solution when one should exist.");
+    const Path& pathc = rc.unwrap();
+    CHECK(!pathc.states.empty(), "RRTConnect path should not be empty");
+    CHECK(space->distance(pathc.states.front(), start_state) < 1e-9, "RRTConnect path should start at the start state");
+    CHECK(space->distance(pathc.states.back(), goal_definition->target()) <= goal_definition->radius(), "RRTConnect path should end in the goal region");
+    CHECK(is_path_valid(pathc, *space, pc), "The RRTConnect path was found to be invalid.");
     std::printf("RRT planner test passed!\n");
     return 0;
 }

@@ -8,7 +8,7 @@ import random
 import pytest
 
 from oxmpl_amd.base import RealVectorState, RealVectorStateSpace, ProblemDefinition, SphereBoxValidityChecker, Path
-from oxmpl_amd.geometric import RRT
+from oxmpl_amd.geometric import RRT, RRTConnect
 
 
 class CircularGoal:
@@ -103,3 +103,21 @@ def test_readme_quickstart_python():
     p2.setup(SphereBoxValidityChecker(spheres=[([0.0, 0.0], 2.0)]))
     with pytest.raises(Exception, match="No solution found|timed out"):
         p2.solve(timeout_secs=0.2)
+
+
+@pytest.mark.gpu
+def test_rrt_connect_finds_path_in_rvss():
+    """oxmpl-py/tests/test_rrt_connect_rvss.py with the import line changed (same scene as the RRT test)"""
+    space = RealVectorStateSpace(dimension=2, bounds=[(0.0, 10.0), (0.0, 10.0)])
+    start_state = RealVectorState([1.0, 5.0])
+    goal_region = CircularGoal(space, x=9.0, y=5.0, radius=0.5)
+    problem_def = ProblemDefinition.from_real_vector(space, start_state, goal_region)
+    planner = RRTConnect(max_distance=0.5, goal_bias=0.05, problem_definition=problem_def)
+    planner.setup(SphereBoxValidityChecker(boxes=[([4.75, 2.0], [5.25, 8.0])]))
+    path = planner.solve(timeout_secs=5.0)
+    assert len(path.states) > 1
+    assert space.distance(path.states[0], start_state) < 1e-9
+    assert goal_region.is_satisfied(path.states[-1])
+    for state in path.states:
+        assert is_state_valid(state), f"Path contains an invalid state: {state.values}"
+    assert planner.num_nodes >= len(path.states)
