@@ -189,7 +189,7 @@ def main():
         }
         if secondary is not None:
             out["secondary"] = secondary
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the contract: rank 0, N = 1 only
             threads = min(os.cpu_count() or 1, 16)
             planners, base = cpu_baseline(sc, seed, threads, 6000)
             out["cpu_baseline"] = base
