@@ -100,3 +100,33 @@ def test_scenarios_match_golden_sphere_field(golden):
     sc = scenarios.config2()
     assert np.array_equal(bits(c), bits(sc["spheres"][0])) and np.array_equal(bits(r), bits(sc["spheres"][1]))
     assert len(r) == 64
+
+
+def test_null_and_range_arguments_are_bad_arg_not_crashes(L):
+    """nothing aborts across the ABI: null handles / pointers come back as OXHIP_ERR_BAD_ARG"""
+    n = C.c_uint32()
+    assert L.oxhip_rrt_batch_create(None, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_set_spheres(None, None, None, 0) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_set_boxes(None, None, None, 0) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_setup(None, None, None, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_solve(None, 10, 0.0, 0, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_get_counts(None, None, None, None, None, None, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_get_tree(None, 0, None, None, 0, C.byref(n)) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_get_path(None, 0, None, 0, C.byref(n)) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_get_goal_counts(None, None, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_last_timing(None, None, None, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_rrt_batch_destroy(None) == capi.OK
+    assert L.oxhip_nn_argmin_batch(0, 3, None, None, 1, None, None, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_distance_batch(0, 0, None, None, 1, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_f64_op_batch(0, 9, None, None, None, 1, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_device_count(None) == capi.ERR_BAD_ARG
+    assert b"null" in L.oxhip_last_error_string() or L.oxhip_last_error_string()
+    with pytest.raises(capi.OxhipError) as ei:   # unknown planner / kernel kinds
+        capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.1, 0.0, 1, 10, planner=7)
+    assert ei.value.status == capi.ERR_BAD_ARG
+    with pytest.raises(capi.OxhipError) as ei:
+        capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.1, 0.0, 1, 10, kernel=9)
+    assert ei.value.status == capi.ERR_BAD_ARG
+    with pytest.raises(capi.OxhipError) as ei:   # RRTConnect has no resident kernel
+        capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.1, 0.0, 1, 10, kernel=capi.KERNEL_RESIDENT, planner=capi.PLANNER_RRT_CONNECT)
+    assert ei.value.status == capi.ERR_BAD_ARG
