@@ -176,9 +176,9 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_BAD_ARG, "goal_bias outside [0,1] (rand Bernoulli::new would fail)");
     if (!(cfg->max_distance > 0.0) || !std::isfinite(cfg->max_distance))
         return fail(OXHIP_ERR_BAD_ARG, "max_distance must be finite and > 0");
-    if (cfg->kernel > OXHIP_KERNEL_RESIDENT) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
+    if (cfg->kernel > OXHIP_KERNEL_PRUNED) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
     if (cfg->planner > OXHIP_PLANNER_RRT_CONNECT) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
-    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel == OXHIP_KERNEL_RESIDENT)
+    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
         return fail(OXHIP_ERR_BAD_ARG, "RRTConnect runs on the stream kernel only");
     for (uint32_t k = 0; k < cfg->dim; ++k) {
         double lo = cfg->bounds[2 * k], hi = cfg->bounds[2 * k + 1];
@@ -254,6 +254,10 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     uint32_t kind = cfg->kernel;
     if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT) kind = OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO) kind = resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
+    if (kind == OXHIP_KERNEL_PRUNED && !pruned_supported(dim, cap)) {
+        oxhip_rrt_batch_destroy(b);
+        return fail(OXHIP_ERR_BAD_ARG, "resident (pruned) kernel does not support this (dim, max_nodes)");
+    }
     if (kind == OXHIP_KERNEL_RESIDENT && !resident_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
         return fail(OXHIP_ERR_BAD_ARG, "resident kernel does not support this (dim, max_nodes)");
@@ -482,6 +486,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         b->dp.freeze = freeze ? 1 : 0;
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
         if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
+        else if (b->kernel_kind == OXHIP_KERNEL_PRUNED) launch_rrt_pruned(b->dp, b->stream);
         else if (b->kernel_kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
         else launch_rrt_stream(b->dp, b->stream);
         HIP_TRY(hipGetLastError());

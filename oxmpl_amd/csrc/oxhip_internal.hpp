@@ -32,4 +32,8 @@ void launch_rrt_connect(const DevParams& p, hipStream_t stream);
 bool resident_supported(uint32_t dim, uint32_t cap);
 void launch_rrt_resident(const DevParams& p, hipStream_t stream);
 
+// rrt_pruned.hip: the resident pipeline + launch-time spatial sort and box-pruned scans
+bool pruned_supported(uint32_t dim, uint32_t cap);
+void launch_rrt_pruned(const DevParams& p, hipStream_t stream);
+
 }  // namespace oxhip

@@ -43,7 +43,8 @@ def test_resident_tree_stays_in_registers(resident_asm):
         assert m["max_flat_workgroup_size"] == 576
         # 9 waves per CU -> at most 3 on a SIMD -> 512/3 = 170 registers per lane
         assert m["vgpr_count"] <= 168, (name, m)
-        assert m["group_segment_fixed_size"] <= 16 * 1024
+        # 14.4 KB of pipeline state + 576 x 24 B the backend promotes from a small private array
+        assert m["group_segment_fixed_size"] <= 32 * 1024
     big = [m for k, m in meta.items() if "Li3ELi21ELb0" in k][0]
     assert big["vgpr_count"] >= 126  # 21 slots x 3 x f64 = 126 VGPRs of tree alone
 
