@@ -14,12 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboxmpl_oracle.so")
 
 SOLVED, TIMEOUT, NO_SOLUTION_FOUND, PLANNER_UNINITIALISED = 0, 1, 2, 3
+INVALID_START_STATE, UNSAMPLED_STATE_SPACE = 4, 5
 BAD_ARG, UNBOUNDED, ZERO_VOLUME = 16, 17, 18
 STOP_GOAL, STOP_ITERATIONS, STOP_NODES, STOP_TIMEOUT = 0, 1, 2, 3
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("rrt_oracle.c", "rrt_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("rrt_oracle.c", "rrt_oracle.h", "prm_oracle.c", "prm_oracle.h", "Makefile")]
     if (not force) and os.path.exists(_LIB_PATH) and all(
             os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src):
         return _LIB_PATH
@@ -102,6 +103,29 @@ def lib():
         L.orc_rrtc_get_path.restype = C.c_uint32
         L.orc_rrt_solve_many.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, C.c_int,
                                          C.c_uint32]
+        _u32p = C.POINTER(C.c_uint32)
+        L.orc_prm_new.argtypes = [C.c_uint32, _dp, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
+                                  C.POINTER(C.c_int)]
+        L.orc_prm_new.restype = C.c_void_p
+        L.orc_prm_free.argtypes = [C.c_void_p]
+        L.orc_prm_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.orc_prm_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.orc_prm_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.orc_prm_set_problem.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.orc_prm_construct_roadmap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.orc_prm_num_milestones.argtypes = [C.c_void_p]
+        L.orc_prm_num_milestones.restype = C.c_uint32
+        for name in ("orc_prm_num_edge_entries", "orc_prm_num_samples"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint64
+        L.orc_prm_get_roadmap.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_uint64), _u32p]
+        L.orc_prm_get_roadmap.restype = None
+        L.orc_prm_solve.argtypes = [C.c_void_p, C.c_double]
+        L.orc_prm_get_path.argtypes = [C.c_void_p, _dp, C.c_uint32]
+        L.orc_prm_get_path.restype = C.c_uint32
+        for name in ("orc_prm_get_start_connections", "orc_prm_get_goal_indices"):
+            getattr(L, name).argtypes = [C.c_void_p, _u32p, C.c_uint32]
+            getattr(L, name).restype = C.c_uint32
         _lib = L
     return _lib
 
@@ -317,3 +341,85 @@ class OracleRRTConnect:
 def solve_many(planners, max_iterations, freeze=False, threads=1):
     arr = (C.c_void_p * len(planners))(*[p.h for p in planners])
     return lib().orc_rrt_solve_many(arr, len(planners), max_iterations, int(freeze), threads)
+
+
+class OraclePRM:
+    """oxmpl's PRM (prm.rs) restated on the CPU: construct_roadmap, get_roadmap, solve."""
+
+    def __init__(self, dim, bounds, connection_radius, timeout=float("inf"), lvs_fraction=0.05, seed=0, stream=0):
+        self.dim = dim
+        b, pb = _d(np.asarray(bounds, dtype=np.float64).reshape(-1))
+        st = C.c_int(0)
+        self._h = lib().orc_prm_new(dim, pb, timeout, connection_radius, lvs_fraction, seed, stream, C.byref(st))
+        self.status = st.value
+        if not self._h:
+            raise ValueError("orc_prm_new failed with status %d" % st.value)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_prm_free(self._h)
+            self._h = None
+
+    def set_spheres(self, centres, radii):
+        c, pc = _d(np.asarray(centres, dtype=np.float64).reshape(-1))
+        r, pr = _d(radii)
+        lib().orc_prm_set_spheres(self._h, pc, pr, len(r))
+
+    def set_boxes(self, lo, hi):
+        l, pl = _d(np.asarray(lo, dtype=np.float64).reshape(-1))
+        h, ph = _d(np.asarray(hi, dtype=np.float64).reshape(-1))
+        lib().orc_prm_set_boxes(self._h, pl, ph, len(l) // self.dim)
+
+    def setup(self, start, goal_centre, goal_radius):
+        s, ps = _d(start)
+        g, pg = _d(goal_centre)
+        return lib().orc_prm_setup(self._h, ps, pg, goal_radius)
+
+    def set_problem(self, start, goal_centre, goal_radius):
+        s, ps = _d(start)
+        g, pg = _d(goal_centre)
+        return lib().orc_prm_set_problem(self._h, ps, pg, goal_radius)
+
+    def construct_roadmap(self, max_milestones, max_samples=2 ** 62):
+        return lib().orc_prm_construct_roadmap(self._h, max_milestones, max_samples)
+
+    @property
+    def num_milestones(self):
+        return lib().orc_prm_num_milestones(self._h)
+
+    @property
+    def num_samples(self):
+        return lib().orc_prm_num_samples(self._h)
+
+    def roadmap(self):
+        """(states [n][dim], offsets [n+1], neighbours [E]) with each node's `edges` in the reference's order"""
+        n = self.num_milestones
+        e = lib().orc_prm_num_edge_entries(self._h)
+        states = np.zeros((n, self.dim), dtype=np.float64)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        nbrs = np.zeros(max(e, 1), dtype=np.uint32)
+        lib().orc_prm_get_roadmap(self._h, states.ctypes.data_as(_dp), offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                  nbrs.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return states, offsets, nbrs[:e]
+
+    def solve(self, timeout_s=float("inf")):
+        return lib().orc_prm_solve(self._h, timeout_s)
+
+    def path(self):
+        n = lib().orc_prm_get_path(self._h, None, 0)
+        out = np.zeros((n, self.dim), dtype=np.float64)
+        if n:
+            lib().orc_prm_get_path(self._h, out.ctypes.data_as(_dp), n)
+        return out
+
+    def start_connections(self):
+        n = lib().orc_prm_get_start_connections(self._h, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        lib().orc_prm_get_start_connections(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return out[:n]
+
+    def goal_indices(self):
+        n = lib().orc_prm_get_goal_indices(self._h, None, 0)
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        lib().orc_prm_get_goal_indices(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
+        return out[:n]

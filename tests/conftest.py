@@ -17,3 +17,10 @@ def golden():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "rrt_golden.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def prm_golden():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "prm_golden.json")) as f:
+        return json.load(f)
