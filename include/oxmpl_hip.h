@@ -196,6 +196,61 @@ int32_t oxhip_f64_op_batch(int32_t device, uint32_t op, const double* a, const d
 /* device RNG self-test: the first n u64 words of the (seed, stream) ChaCha12 stream */
 int32_t oxhip_rng_u64_batch(int32_t device, uint64_t seed, uint64_t stream, uint32_t n, uint64_t* out);
 
+/* ---- PRM: replaces geometric::PRM (oxmpl/src/geometric/planners/prm.rs) ----
+ *
+ * PRM::new(timeout, connection_radius) (prm.rs:70-78) + RealVectorStateSpace::new.  The reference builds
+ * its roadmap for `timeout` seconds of wall clock with an OS-seeded RNG; the device path adds the
+ * deterministic caps max_milestones / max_samples (checked where the reference reads its clock,
+ * prm.rs:118) and a ChaCha12 stream (seed, stream) restarted by setup().  For a given final milestone
+ * count the roadmap does not depend on how construction was batched. */
+typedef struct oxhip_prm_config {
+    uint32_t struct_size;               /* = sizeof(oxhip_prm_config) */
+    uint32_t dim;                       /* 1..OXHIP_MAX_DIM */
+    double   bounds[2 * OXHIP_MAX_DIM]; /* (lo,hi) pairs */
+    double   timeout;                   /* PRM::timeout (prm.rs:50), seconds of construction; read between
+                                           device rounds; <= 0 or inf: no wall-clock bound */
+    double   connection_radius;         /* PRM::connection_radius (prm.rs:52): edge iff distance < radius (strict) */
+    double   lvs_fraction;              /* longest_valid_segment_fraction, default 0.05 */
+    uint32_t max_milestones;            /* construct_roadmap stops at this many milestones (build-defined) */
+    int32_t  device;                    /* HIP device ordinal */
+    uint64_t max_samples;               /* ... or after this many sample_uniform calls; 0 = unlimited */
+    uint64_t seed;                      /* ChaCha12 key = LE(seed)||0^24 */
+    uint64_t stream;                    /* ChaCha12 stream id */
+} oxhip_prm_config;
+
+typedef struct oxhip_prm oxhip_prm;
+
+int32_t oxhip_prm_create(const oxhip_prm_config* cfg, oxhip_prm** out);
+int32_t oxhip_prm_destroy(oxhip_prm* prm);
+/* the device-describable StateValidityChecker, as for the RRT batch */
+int32_t oxhip_prm_set_spheres(oxhip_prm* prm, const double* centres /*[n][dim]*/, const double* radii, uint32_t n);
+int32_t oxhip_prm_set_boxes(oxhip_prm* prm, const double* lo /*[n][dim]*/, const double* hi, uint32_t n);
+/* Planner::setup (prm.rs:217-225): stores start / ball goal, clears the roadmap, restarts the RNG stream */
+int32_t oxhip_prm_setup(oxhip_prm* prm, const double* start, const double* goal_centre, double goal_radius);
+/* PRM::set_problem_definition (prm.rs:88-90): new start / goal, roadmap kept (multi-query use) */
+int32_t oxhip_prm_set_problem(oxhip_prm* prm, const double* start, const double* goal_centre, double goal_radius);
+/* PRM::construct_roadmap (prm.rs:96-154); a no-op when a roadmap exists (prm.rs:106-113) */
+int32_t oxhip_prm_construct_roadmap(oxhip_prm* prm);
+/* roadmap.len(), sum of edges.len() over all nodes (= 2 x undirected edges), sample_uniform calls made */
+int32_t oxhip_prm_get_sizes(oxhip_prm* prm, uint32_t* n_milestones, uint64_t* n_edge_entries, uint64_t* n_samples);
+/* PRM::get_roadmap (prm.rs:82-84): states AoS [n][dim]; node i's `edges` = neighbours[offsets[i] .. offsets[i+1]),
+ * in the reference's order (ascending).  Any pointer may be NULL. */
+int32_t oxhip_prm_get_roadmap(oxhip_prm* prm, double* states, uint32_t cap_nodes, uint64_t* offsets /*[n+1]*/,
+                              uint32_t* neighbours, uint64_t cap_entries);
+/* Planner::solve (prm.rs:227-307): OXHIP_OK and the path [start, milestones...] (prm.rs:189-208), or
+ * OXHIP_ERR_PLANNER_UNINITIALISED / _UNSAMPLED_STATE_SPACE / _INVALID_START_STATE / _NO_SOLUTION_FOUND /
+ * _TIMEOUT (graph search, prm.rs:285-287; timeout_s <= 0 or inf: none).  path may be NULL (length only). */
+int32_t oxhip_prm_solve(oxhip_prm* prm, double timeout_s, double* path /*[cap_states][dim]*/, uint32_t cap_states,
+                        uint32_t* len);
+/* start_connections / goal_indices of the last solve (prm.rs:249-264) */
+int32_t oxhip_prm_get_query_sets(oxhip_prm* prm, uint32_t* start_connections, uint32_t cap_start, uint32_t* n_start,
+                                 uint32_t* goal_indices, uint32_t cap_goal, uint32_t* n_goal);
+/* HIP-event times (ms) of the last construct_roadmap / solve: phase_ms[6] = {sampling, all-pairs radius
+ * search, edge check_motion, key sort + CSR, query kernel, host BFS}; in-radius pairs examined; sample batches
+ * replayed because rand's range sampler rejected a draw */
+int32_t oxhip_prm_last_timing(oxhip_prm* prm, double* phase_ms /*[6]*/, uint64_t* n_candidates,
+                              uint32_t* redraw_batches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,9 @@ EXPORTS = [
     "oxhip_nn_argmin_batch", "oxhip_distance_batch",
     "oxhip_interpolate_batch", "oxhip_rrt_batch_is_valid", "oxhip_rrt_batch_check_motion",
     "oxhip_f64_op_batch", "oxhip_rng_u64_batch",
+    "oxhip_prm_create", "oxhip_prm_destroy", "oxhip_prm_set_spheres", "oxhip_prm_set_boxes", "oxhip_prm_setup",
+    "oxhip_prm_set_problem", "oxhip_prm_construct_roadmap", "oxhip_prm_get_sizes", "oxhip_prm_get_roadmap",
+    "oxhip_prm_solve", "oxhip_prm_get_query_sets", "oxhip_prm_last_timing",
 ]
 
 
@@ -41,6 +44,15 @@ class Config(C.Structure):
         ("n_problems", C.c_uint32), ("max_nodes", C.c_uint32), ("stop_at_goal", C.c_uint32),
         ("kernel", C.c_uint32), ("seed", C.c_uint64), ("first_problem_id", C.c_uint64),
         ("device", C.c_int32), ("planner", C.c_uint32),
+    ]
+
+
+class PrmConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("dim", C.c_uint32), ("bounds", C.c_double * (2 * MAX_DIM)),
+        ("timeout", C.c_double), ("connection_radius", C.c_double), ("lvs_fraction", C.c_double),
+        ("max_milestones", C.c_uint32), ("device", C.c_int32), ("max_samples", C.c_uint64),
+        ("seed", C.c_uint64), ("stream", C.c_uint64),
     ]
 
 
@@ -107,6 +119,18 @@ def lib():
         L.oxhip_rrt_batch_check_motion.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32, _u8p]
         L.oxhip_f64_op_batch.argtypes = [C.c_int32, C.c_uint32, _dp, _dp, _dp, C.c_uint32, _dp]
         L.oxhip_rng_u64_batch.argtypes = [C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, _u64p]
+        L.oxhip_prm_create.argtypes = [C.POINTER(PrmConfig), C.POINTER(C.c_void_p)]
+        L.oxhip_prm_destroy.argtypes = [C.c_void_p]
+        L.oxhip_prm_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.oxhip_prm_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.oxhip_prm_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.oxhip_prm_set_problem.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.oxhip_prm_construct_roadmap.argtypes = [C.c_void_p]
+        L.oxhip_prm_get_sizes.argtypes = [C.c_void_p, _u32p, _u64p, _u64p]
+        L.oxhip_prm_get_roadmap.argtypes = [C.c_void_p, _dp, C.c_uint32, _u64p, _u32p, C.c_uint64]
+        L.oxhip_prm_solve.argtypes = [C.c_void_p, C.c_double, _dp, C.c_uint32, _u32p]
+        L.oxhip_prm_get_query_sets.argtypes = [C.c_void_p, _u32p, C.c_uint32, _u32p, _u32p, C.c_uint32, _u32p]
+        L.oxhip_prm_last_timing.argtypes = [C.c_void_p, _dp, _u64p, _u32p]
         for name in EXPORTS:
             if name not in ("oxhip_status_string", "oxhip_last_error_string"):
                 getattr(L, name).restype = C.c_int32
@@ -319,3 +343,96 @@ def rng_u64_batch(seed, stream, n, device=0):
     out = np.empty(n, dtype=np.uint64)
     _check(lib().oxhip_rng_u64_batch(device, seed, stream, n, _p(out, _u64p)))
     return out
+
+
+class PRMRoadmap:
+    """oxmpl's PRM (prm.rs) on one GPU: roadmap construction and queries.  Thin wrapper of oxhip_prm_*."""
+
+    def __init__(self, dim, bounds, connection_radius, max_milestones, timeout=0.0, lvs_fraction=0.05,
+                 max_samples=0, seed=0, stream=0, device=0):
+        cfg = PrmConfig()
+        cfg.struct_size = C.sizeof(PrmConfig)
+        cfg.dim = dim
+        b = _f64(bounds).reshape(-1)
+        if b.size != 2 * dim:
+            raise OxhipError(ERR_BAD_ARG, "bounds must hold dim (lo,hi) pairs")
+        for i, v in enumerate(b[:2 * MAX_DIM]):
+            cfg.bounds[i] = v
+        cfg.timeout, cfg.connection_radius, cfg.lvs_fraction = timeout, connection_radius, lvs_fraction
+        cfg.max_milestones, cfg.device, cfg.max_samples = max_milestones, device, max_samples
+        cfg.seed, cfg.stream = seed, stream
+        self.dim = dim
+        self._h = C.c_void_p()
+        _check(lib().oxhip_prm_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().oxhip_prm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_spheres(self, centres, radii):
+        r = _f64(radii).reshape(-1)
+        c = _f64(centres, (r.size, self.dim))
+        _check(lib().oxhip_prm_set_spheres(self._h, _p(c), _p(r), r.size))
+
+    def set_boxes(self, lo, hi):
+        lo = _f64(lo).reshape(-1, self.dim)
+        hi = _f64(hi, lo.shape)
+        _check(lib().oxhip_prm_set_boxes(self._h, _p(lo), _p(hi), lo.shape[0]))
+
+    def setup(self, start, goal_centre, goal_radius):
+        s, g = _f64(start, (self.dim,)), _f64(goal_centre, (self.dim,))
+        _check(lib().oxhip_prm_setup(self._h, _p(s), _p(g), goal_radius))
+
+    def set_problem(self, start, goal_centre, goal_radius):
+        s, g = _f64(start, (self.dim,)), _f64(goal_centre, (self.dim,))
+        _check(lib().oxhip_prm_set_problem(self._h, _p(s), _p(g), goal_radius))
+
+    def construct_roadmap(self):
+        _check(lib().oxhip_prm_construct_roadmap(self._h))
+
+    def sizes(self):
+        """(milestones, edge entries = 2 x undirected edges, samples drawn)"""
+        n, e, s = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(lib().oxhip_prm_get_sizes(self._h, C.byref(n), C.byref(e), C.byref(s)))
+        return n.value, e.value, s.value
+
+    def roadmap(self):
+        """(states [n][dim], offsets [n+1] u64, neighbours [E] u32)"""
+        n, e, _ = self.sizes()
+        states = np.zeros((n, self.dim), dtype=np.float64)
+        offsets = np.zeros(n + 1, dtype=np.uint64)
+        nbrs = np.zeros(max(e, 1), dtype=np.uint32)
+        _check(lib().oxhip_prm_get_roadmap(self._h, _p(states), n, _p(offsets, _u64p), _p(nbrs, _u32p), e))
+        return states, offsets, nbrs[:e]
+
+    def solve(self, timeout_s=0.0):
+        """Planner::solve: returns (status, path [len][dim]); the status codes mirror PlanningError"""
+        ln = C.c_uint32()
+        st = lib().oxhip_prm_solve(self._h, timeout_s, None, 0, C.byref(ln))
+        if st != OK:
+            if st in (ERR_TIMEOUT, ERR_NO_SOLUTION_FOUND, ERR_PLANNER_UNINITIALISED, ERR_INVALID_START_STATE,
+                      ERR_UNSAMPLED_STATE_SPACE):
+                return st, np.zeros((0, self.dim))
+            _check(st)
+        path = np.zeros((ln.value, self.dim), dtype=np.float64)
+        _check(lib().oxhip_prm_solve(self._h, timeout_s, _p(path), ln.value, C.byref(ln)))
+        return OK, path
+
+    def query_sets(self):
+        ns, ng = C.c_uint32(), C.c_uint32()
+        _check(lib().oxhip_prm_get_query_sets(self._h, None, 0, C.byref(ns), None, 0, C.byref(ng)))
+        sc = np.zeros(max(ns.value, 1), dtype=np.uint32)
+        gi = np.zeros(max(ng.value, 1), dtype=np.uint32)
+        _check(lib().oxhip_prm_get_query_sets(self._h, _p(sc, _u32p), ns.value, C.byref(ns), _p(gi, _u32p), ng.value,
+                                              C.byref(ng)))
+        return sc[:ns.value], gi[:ng.value]
+
+    def last_timing(self):
+        """dict(phase_ms=[sample, pairs, edges, sort+csr, query, bfs], candidates, redraw_batches)"""
+        ms = np.zeros(6, dtype=np.float64)
+        c, r = C.c_uint64(), C.c_uint32()
+        _check(lib().oxhip_prm_last_timing(self._h, _p(ms), C.byref(c), C.byref(r)))
+        return dict(phase_ms=[float(v) for v in ms], candidates=c.value, redraw_batches=r.value)

@@ -16,100 +16,11 @@
 #include <string>
 #include <vector>
 
+#include "oxhip_host.hpp"
 #include "oxhip_internal.hpp"
 #include "rrt_device.hpp"
 
 using namespace oxhip;
-
-namespace {
-
-thread_local std::string g_last_error;
-
-int32_t fail(int32_t code, const std::string& msg) {
-    g_last_error = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                           \
-    do {                                                                                        \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-            return fail(OXHIP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
-    } while (0)
-
-int32_t select_device(int32_t device) {
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0)
-        return fail(OXHIP_ERR_NO_DEVICE, "no HIP device visible (liboxmpl_hip has no CPU fallback)");
-    if (device < 0 || device >= count) return fail(OXHIP_ERR_BAD_ARG, "device ordinal out of range");
-    HIP_TRY(hipSetDevice(device));
-    return OXHIP_OK;
-}
-
-// largest x with sqrt(x) <= r under correctly rounded binary64 sqrt, so that
-//   sqrt(d2) >  r  <=>  d2 >  T      (sphere validity, strict)
-//   sqrt(d2) <= r  <=>  d2 <= T      (ball goal)
-// hold exactly and the kernels need no sqrt per obstacle.  r < 0 -> -1, NaN -> NaN.
-double sqrt_le_threshold(double r) {
-    if (std::isnan(r)) return r;
-    if (r < 0.0) return -1.0;
-    if (std::isinf(r)) return r;
-    double x = r * r;
-    if (std::isinf(x)) x = std::numeric_limits<double>::max();
-    while (std::sqrt(x) > r) x = std::nextafter(x, -1.0);
-    for (;;) {
-        double y = std::nextafter(x, std::numeric_limits<double>::infinity());
-        if (std::isinf(y) || std::sqrt(y) > r) break;
-        x = y;
-    }
-    return x;
-}
-
-// rand 0.9 Bernoulli::new
-uint64_t bernoulli_p_int(double p) {
-    if (p == 1.0) return ~0ull;
-    double v = p * 18446744073709551616.0;
-    if (!(v > 0.0)) return 0;
-    if (v >= 18446744073709551616.0) return ~0ull;
-    return (uint64_t)v;
-}
-
-constexpr double kMaxMagnitude = 1e150;  // keeps every squared difference finite
-
-template <typename T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t count) {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        n = count;
-        if (count == 0) return hipSuccess;
-        return hipMalloc((void**)&p, count * sizeof(T));
-    }
-};
-
-}  // namespace
-
-namespace {
-struct TmpStream {
-    hipStream_t s = nullptr;
-    ~TmpStream() { if (s) (void)hipStreamDestroy(s); }
-};
-template <typename T>
-int32_t to_device(DevBuf<T>& buf, const T* host, size_t n, hipStream_t s) {
-    HIP_TRY(buf.alloc(n));
-    if (n) HIP_TRY(hipMemcpyAsync(buf.p, host, n * sizeof(T), hipMemcpyHostToDevice, s));
-    return OXHIP_OK;
-}
-template <typename T>
-int32_t to_host(T* host, const DevBuf<T>& buf, size_t n, hipStream_t s) {
-    if (n) HIP_TRY(hipMemcpyAsync(host, buf.p, n * sizeof(T), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return OXHIP_OK;
-}
-}  // namespace
 
 struct oxhip_rrt_batch {
     oxhip_rrt_config cfg{};
@@ -180,28 +91,11 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (cfg->planner > OXHIP_PLANNER_RRT_CONNECT) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
     if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
         return fail(OXHIP_ERR_BAD_ARG, "RRTConnect runs on the stream kernel only");
-    for (uint32_t k = 0; k < cfg->dim; ++k) {
-        double lo = cfg->bounds[2 * k], hi = cfg->bounds[2 * k + 1];
-        if (!std::isfinite(lo) || !std::isfinite(hi))  // real_vector_state_space.rs:239-241
-            return fail(OXHIP_ERR_UNBOUNDED, "dimension " + std::to_string(k) + " is unbounded");
-        if (lo >= hi) return fail(OXHIP_ERR_ZERO_VOLUME, "lower bound >= upper bound");  // rvss.rs:78-83,242-244
-        if (std::fabs(lo) > kMaxMagnitude || std::fabs(hi) > kMaxMagnitude)
-            return fail(OXHIP_ERR_BAD_ARG, "bounds beyond 1e150 would overflow squared distances");
+    double fraction = cfg->lvs_fraction, res = 0.0;
+    {
+        int32_t sr = space_resolution(cfg->dim, cfg->bounds, fraction, res);
+        if (sr != OXHIP_OK) return sr;
     }
-    // set_longest_valid_segment_fraction clamp (rvss.rs:121-129)
-    double fraction = cfg->lvs_fraction;
-    if (fraction > 0.0 && fraction <= 1.0) {} else if (fraction <= 0.0) fraction = 0.0; else fraction = 1.0;
-    // get_maximum_extent (rvss.rs:103-118): sequential sum of squared widths, sqrt
-    double acc = 0.0;
-    for (uint32_t k = 0; k < cfg->dim; ++k) {
-        double w = cfg->bounds[2 * k + 1] - cfg->bounds[2 * k];
-        double sq = w * w;
-        acc = acc + sq;
-    }
-    double extent = std::sqrt(acc);
-    double lvsl = extent * fraction;  // rvss.rs:251-253
-    double res = lvsl * 0.1;          // rrt.rs:97
-    if (!(res > 0.0)) return fail(OXHIP_ERR_BAD_ARG, "longest valid segment length is 0: check_motion would never terminate");
     if (cfg->max_distance / res > 1e6) return fail(OXHIP_ERR_BAD_ARG, "more than 1e6 validity checks per edge");
 
     int32_t st = select_device(cfg->device);
@@ -275,15 +169,6 @@ int32_t oxhip_rrt_batch_destroy(oxhip_rrt_batch* b) {
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
-    return OXHIP_OK;
-}
-
-static int32_t upload(DevBuf<double>& buf, const std::vector<double>& host, hipStream_t s) {
-    HIP_TRY(buf.alloc(host.size()));
-    if (!host.empty()) {
-        HIP_TRY(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
     return OXHIP_OK;
 }
 
@@ -700,8 +585,6 @@ int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out) {
 }
 
 // ------------------------------------------------------------------ stand-alone primitives
-
-#define OX_TRY(expr) do { int32_t s_ = (expr); if (s_ != OXHIP_OK) return s_; } while (0)
 
 int32_t oxhip_nn_argmin_batch(int32_t device, uint32_t dim, const double* nodes, const uint32_t* n_nodes,
                               uint32_t n_queries, const double* queries, uint32_t* out_index, double* out_min_dist) {

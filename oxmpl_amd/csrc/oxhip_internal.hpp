@@ -36,4 +36,40 @@ void launch_rrt_resident(const DevParams& p, hipStream_t stream);
 bool pruned_supported(uint32_t dim, uint32_t cap);
 void launch_rrt_pruned(const DevParams& p, hipStream_t stream);
 
+// prm_kernels.hip: PRM roadmap construction / query (prm.rs)
+struct PrmState {            // persists in HBM between launches
+    uint64_t draws;          // u64 words consumed from the ChaCha12 stream
+    uint64_t n_samples;      // sample_uniform calls made (prm.rs:122)
+    unsigned long long n_cand;  // in-radius pairs counted by the current pairs launch (beyond cand_cap: not stored)
+    uint32_t n_milestones;   // roadmap.len()
+    uint32_t n_keys;         // directed edge keys appended so far (2 per undirected edge)
+    uint32_t redraw_batches; // sample batches replayed sequentially because rand rejected a draw
+    uint32_t pad;
+};
+struct PrmArgs {
+    double* ms;              // milestones, SoA [dim][cap]
+    uint32_t cap;
+    uint32_t n_target;       // sample until the roadmap holds this many milestones ...
+    uint64_t max_samples;    // ... or this many samples were drawn
+    uint64_t stream;         // ChaCha12 stream id (the key is DevParams::seed)
+    PrmState* state;
+    uint2* cand;             // (j, i) with i < j and distance < connection_radius
+    uint32_t cand_cap;
+    uint64_t* keys;          // (u << 32) | v for every directed edge u -> v
+};
+struct PrmQuery {
+    double start[8], goal_c[8];
+    double goal_thr;         // satisfied iff d2 <= goal_thr
+};
+void launch_prm_sample(const DevParams& p, const PrmArgs& a, hipStream_t s);
+void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_t j1, double thr, hipStream_t s);
+void launch_prm_edges(const DevParams& p, const PrmArgs& a, uint32_t n_cand, hipStream_t s);
+// rocPRIM radix sort of the directed keys; tmp == nullptr queries tmp_bytes
+hipError_t prm_sort_keys(void* tmp, size_t& tmp_bytes, uint64_t* in, uint64_t* out, uint32_t n_keys, uint32_t n_nodes,
+                         hipStream_t s);
+void launch_prm_csr(const uint64_t* sorted, uint32_t n_keys, uint32_t n_nodes, uint32_t* offsets, uint32_t* nbrs,
+                    hipStream_t s);
+void launch_prm_query(const DevParams& p, const PrmArgs& a, uint32_t n, const PrmQuery& q, double thr, uint8_t* flags,
+                      uint32_t* start_valid, hipStream_t s);
+
 }  // namespace oxhip

@@ -1,0 +1,448 @@
+// oxhip_prm_api.hip -- the PRM part of the C ABI (include/oxmpl_hip.h, oxhip_prm_*).
+//
+// Host side of oxmpl's PRM (oxmpl/src/geometric/planners/prm.rs): owns the device roadmap, drives
+// the construction phases of prm_kernels.hip, and runs the breadth-first query (prm.rs:270-307) and
+// reconstruct_path (prm.rs:189-208) on the CSR roadmap it copies back once per construction.  Start
+// validity, start connections and goal milestones (prm.rs:243-264) are computed on the device.
+// There is no CPU fallback: without a HIP device every computing entry point fails.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <deque>
+
+#include "oxhip_host.hpp"
+#include "oxhip_internal.hpp"
+#include "rrt_device.hpp"
+
+using namespace oxhip;
+
+struct oxhip_prm {
+    oxhip_prm_config cfg{};
+    DevParams dp{};           // space, resolution and validity field (the RRT fields stay zero)
+    PrmArgs args{};
+    double thr_conn = -1.0;   // d2 <= thr_conn  <=>  distance < connection_radius
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    DevBuf<double> ms, sph_c, sph_thr, box_lo, box_hi;
+    DevBuf<PrmState> state;
+    DevBuf<uint2> cand;
+    DevBuf<uint64_t> keys, keys_sorted;
+    DevBuf<uint32_t> offsets, nbrs, start_valid;
+    DevBuf<uint8_t> flags;
+    bool is_setup = false;
+    PrmQuery query{};
+    // host copy of the constructed roadmap
+    uint32_t n = 0;
+    uint64_t n_samples = 0;
+    uint32_t redraw_batches = 0;
+    std::vector<uint32_t> h_offsets, h_nbrs;
+    std::vector<double> h_states;  // AoS [n][dim]
+    // last query
+    std::vector<uint32_t> start_conn, goal_idx;
+    // phase timings of the last construct / solve (ms): sample, pairs, edges, sort+csr, query kernel, bfs (host)
+    double t_ms[6] = {};
+    uint64_t n_candidates = 0;
+};
+
+namespace {
+
+int32_t read_state(oxhip_prm* h, PrmState& st) {
+    HIP_TRY(hipMemcpyAsync(&st, h->state.p, sizeof(PrmState), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return OXHIP_OK;
+}
+
+int32_t write_state(oxhip_prm* h, const PrmState& st) {
+    HIP_TRY(hipMemcpyAsync(h->state.p, &st, sizeof(PrmState), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return OXHIP_OK;
+}
+
+int32_t set_query(oxhip_prm* h, const double* start, const double* goal_centre, double goal_radius) {
+    const uint32_t dim = h->cfg.dim;
+    for (uint32_t k = 0; k < dim; ++k)
+        if (!(std::fabs(start[k]) <= kMaxMagnitude) || !(std::fabs(goal_centre[k]) <= kMaxMagnitude))
+            return fail(OXHIP_ERR_BAD_ARG, "start / goal centre not finite or beyond 1e150");
+    h->query = PrmQuery{};
+    std::memcpy(h->query.start, start, dim * sizeof(double));
+    std::memcpy(h->query.goal_c, goal_centre, dim * sizeof(double));
+    h->query.goal_thr = sqrt_le_threshold(goal_radius);
+    return OXHIP_OK;
+}
+
+void clear_roadmap(oxhip_prm* h) {
+    h->n = 0;
+    h->n_samples = 0;
+    h->redraw_batches = 0;
+    h->h_offsets.clear();
+    h->h_nbrs.clear();
+    h->h_states.clear();
+    h->start_conn.clear();
+    h->goal_idx.clear();
+}
+
+double elapsed_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    return hipEventElapsedTime(&ms, a, b) == hipSuccess ? (double)ms : 0.0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t oxhip_prm_create(const oxhip_prm_config* cfg, oxhip_prm** out) {
+    if (!cfg || !out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(oxhip_prm_config)) return fail(OXHIP_ERR_BAD_ARG, "struct_size mismatch");
+    if (cfg->max_milestones == 0 || cfg->max_milestones > (1u << 26))
+        return fail(OXHIP_ERR_BAD_ARG, "max_milestones must be in 1..2^26");
+    if (std::isnan(cfg->connection_radius)) return fail(OXHIP_ERR_BAD_ARG, "connection_radius is NaN");
+    double fraction = cfg->lvs_fraction, res = 0.0;
+    OX_TRY(space_resolution(cfg->dim, cfg->bounds, fraction, res));
+    // the longest motion PRM ever checks is shorter than the connection radius
+    if (std::isfinite(cfg->connection_radius) && cfg->connection_radius / res > 1e6)
+        return fail(OXHIP_ERR_BAD_ARG, "more than 1e6 validity checks per edge");
+    OX_TRY(select_device(cfg->device));
+
+    auto* h = new oxhip_prm();
+    h->cfg = *cfg;
+    h->cfg.lvs_fraction = fraction;
+    const uint32_t dim = cfg->dim;
+    const uint32_t cap = ((cfg->max_milestones + 1023u) / 1024u) * 1024u;
+    DevParams& dp = h->dp;
+    dp.dim = dim;
+    for (uint32_t k = 0; k < dim; ++k) {
+        dp.lo[k] = cfg->bounds[2 * k];
+        dp.hi[k] = cfg->bounds[2 * k + 1];
+        dp.scale[k] = dp.hi[k] - dp.lo[k];
+    }
+    dp.res = res;
+    dp.seed = cfg->seed;
+    h->thr_conn = sqrt_lt_threshold(cfg->connection_radius);
+
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
+    chk(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto& ev : h->ev) chk(hipEventCreate(&ev));
+    chk(h->ms.alloc((size_t)dim * cap));
+    chk(h->state.alloc(1));
+    chk(h->flags.alloc(cap));
+    chk(h->start_valid.alloc(1));
+    chk(h->offsets.alloc((size_t)cap + 1));
+    if (e != hipSuccess) {
+        std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e);
+        oxhip_prm_destroy(h);
+        return fail(OXHIP_ERR_HIP, msg);
+    }
+    h->args.ms = h->ms.p;
+    h->args.cap = cap;
+    h->args.stream = cfg->stream;
+    h->args.state = h->state.p;
+    *out = h;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_prm_destroy(oxhip_prm* h) {
+    if (!h) return OXHIP_OK;
+    (void)hipSetDevice(h->cfg.device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_prm_set_spheres(oxhip_prm* h, const double* centres, const double* radii, uint32_t n) {
+    if (!h || (n && (!centres || !radii))) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    OX_TRY(select_device(h->cfg.device));
+    const uint32_t dim = h->cfg.dim;
+    std::vector<double> c((size_t)dim * n), thr(n);
+    for (uint32_t j = 0; j < n; ++j) {
+        for (uint32_t k = 0; k < dim; ++k) {
+            double v = centres[(size_t)j * dim + k];
+            if (!(std::fabs(v) <= kMaxMagnitude)) return fail(OXHIP_ERR_BAD_ARG, "sphere centre not finite / too large");
+            c[(size_t)k * n + j] = v;  // SoA [dim][n]
+        }
+        thr[j] = sqrt_le_threshold(radii[j]);
+    }
+    OX_TRY(upload(h->sph_c, c, h->stream));
+    OX_TRY(upload(h->sph_thr, thr, h->stream));
+    h->dp.n_spheres = n; h->dp.sph_c = h->sph_c.p; h->dp.sph_thr = h->sph_thr.p;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_prm_set_boxes(oxhip_prm* h, const double* lo, const double* hi, uint32_t n) {
+    if (!h || (n && (!lo || !hi))) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    OX_TRY(select_device(h->cfg.device));
+    const uint32_t dim = h->cfg.dim;
+    std::vector<double> l((size_t)dim * n), u((size_t)dim * n);
+    for (uint32_t j = 0; j < n; ++j)
+        for (uint32_t k = 0; k < dim; ++k) {
+            l[(size_t)k * n + j] = lo[(size_t)j * dim + k];
+            u[(size_t)k * n + j] = hi[(size_t)j * dim + k];
+        }
+    OX_TRY(upload(h->box_lo, l, h->stream));
+    OX_TRY(upload(h->box_hi, u, h->stream));
+    h->dp.n_boxes = n; h->dp.box_lo = h->box_lo.p; h->dp.box_hi = h->box_hi.p;
+    return OXHIP_OK;
+}
+
+// Planner::setup (prm.rs:217-225)
+int32_t oxhip_prm_setup(oxhip_prm* h, const double* start, const double* goal_centre, double goal_radius) {
+    if (!h || !start || !goal_centre) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    OX_TRY(select_device(h->cfg.device));
+    OX_TRY(set_query(h, start, goal_centre, goal_radius));
+    clear_roadmap(h);  // self.roadmap.clear()
+    PrmState st{};
+    OX_TRY(write_state(h, st));
+    h->is_setup = true;
+    return OXHIP_OK;
+}
+
+// set_problem_definition (prm.rs:88-90): the roadmap is kept
+int32_t oxhip_prm_set_problem(oxhip_prm* h, const double* start, const double* goal_centre, double goal_radius) {
+    if (!h || !start || !goal_centre) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    return set_query(h, start, goal_centre, goal_radius);
+}
+
+// construct_roadmap (prm.rs:96-154)
+int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
+    if (!h) return fail(OXHIP_ERR_BAD_ARG, "null handle");
+    if (!h->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");  // prm.rs:97-104
+    if (h->n != 0) return OXHIP_OK;  // prm.rs:106-113: "Roadmap already constructed"
+    OX_TRY(select_device(h->cfg.device));
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool has_timeout = h->cfg.timeout > 0.0 && std::isfinite(h->cfg.timeout);
+    const uint32_t n_max = h->cfg.max_milestones;
+    const uint64_t max_samples = h->cfg.max_samples ? h->cfg.max_samples : ~0ull;
+    for (double& t : h->t_ms) t = 0.0;
+    h->n_candidates = 0;
+    PrmState st{};
+    OX_TRY(write_state(h, st));
+    // without a wall clock the roadmap is built in one round; with one, in doubling rounds with the
+    // clock read in between (the reference reads it before every sample, prm.rs:118)
+    uint32_t target = has_timeout ? std::min<uint32_t>(n_max, 4096u) : n_max;
+    uint32_t n_done = 0;  // milestones whose pairs are already connected
+    for (;;) {
+        // ---- 1. sample until `target` milestones
+        h->args.n_target = target;
+        h->args.max_samples = max_samples;
+        HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+        launch_prm_sample(h->dp, h->args, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+        OX_TRY(read_state(h, st));
+        h->t_ms[0] += elapsed_ms(h->ev[0], h->ev[1]);
+        const uint32_t n_now = st.n_milestones;
+        // ---- 2. pairs (j in [n_done, n_now), i < j) within the connection radius
+        if (n_now > n_done && n_now >= 2 && h->thr_conn >= 0.0) {
+            if (h->cand.n == 0) {
+                HIP_TRY(h->cand.alloc(std::min<size_t>(std::max<size_t>(1u << 20, (size_t)64 * n_max), (size_t)1 << 28)));
+                h->args.cand = h->cand.p;
+                h->args.cand_cap = (uint32_t)h->cand.n;
+            }
+            for (;;) {
+                st.n_cand = 0;
+                OX_TRY(write_state(h, st));
+                HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+                launch_prm_pairs(h->dp, h->args, n_done, n_now, h->thr_conn, h->stream);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+                PrmState s2{};
+                OX_TRY(read_state(h, s2));
+                h->t_ms[1] += elapsed_ms(h->ev[2], h->ev[3]);
+                st.n_cand = s2.n_cand;
+                if (st.n_cand <= h->args.cand_cap) break;
+                // candidate buffer too small: the kernel kept counting, so the exact need is known; run again
+                if (st.n_cand > 0x7FFFFFFFull) return fail(OXHIP_ERR_CAPACITY, "more than 2^31 in-radius pairs in one round");
+                HIP_TRY(h->cand.alloc((size_t)st.n_cand));
+                h->args.cand = h->cand.p;
+                h->args.cand_cap = (uint32_t)st.n_cand;
+            }
+            h->n_candidates += st.n_cand;
+            // ---- 3. check_motion per candidate; keys grow by at most 2 per candidate
+            const uint64_t need = (uint64_t)st.n_keys + 2ull * st.n_cand;
+            if (need > 0xFFFFFFFFull) return fail(OXHIP_ERR_CAPACITY, "more than 2^32 directed edges");
+            if (need > h->keys.n) {
+                DevBuf<uint64_t> bigger;
+                HIP_TRY(bigger.alloc(std::max<size_t>((size_t)need, h->keys.n * 2)));
+                if (st.n_keys)
+                    HIP_TRY(hipMemcpyAsync(bigger.p, h->keys.p, (size_t)st.n_keys * sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                                           h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                std::swap(bigger.p, h->keys.p);
+                std::swap(bigger.n, h->keys.n);
+                h->args.keys = h->keys.p;
+            }
+            HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+            launch_prm_edges(h->dp, h->args, (uint32_t)st.n_cand, h->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+            OX_TRY(read_state(h, st));
+            h->t_ms[2] += elapsed_ms(h->ev[2], h->ev[3]);
+        }
+        n_done = n_now;
+        if (n_now < target) break;                       // max_samples exhausted
+        if (n_now >= n_max) break;
+        if (has_timeout && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > h->cfg.timeout)
+            break;                                       // prm.rs:118-120
+        target = target > n_max / 2 ? n_max : target * 2;
+    }
+    // ---- 4. sort the directed keys -> every node's neighbours in ascending order (the reference's `edges`)
+    const uint32_t n = st.n_milestones, n_keys = st.n_keys;
+    HIP_TRY(hipEventRecord(h->ev[4], h->stream));
+    if (n_keys) {
+        HIP_TRY(h->keys_sorted.alloc(n_keys));
+        HIP_TRY(h->nbrs.alloc(n_keys));
+        size_t tmp_bytes = 0;
+        HIP_TRY(prm_sort_keys(nullptr, tmp_bytes, h->keys.p, h->keys_sorted.p, n_keys, n, h->stream));
+        DevBuf<uint8_t> tmp;
+        HIP_TRY(tmp.alloc(tmp_bytes ? tmp_bytes : 1));
+        HIP_TRY(prm_sort_keys(tmp.p, tmp_bytes, h->keys.p, h->keys_sorted.p, n_keys, n, h->stream));
+        launch_prm_csr(h->keys_sorted.p, n_keys, n, h->offsets.p, h->nbrs.p, h->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));  // tmp is freed at scope exit
+    } else {
+        HIP_TRY(hipMemsetAsync(h->offsets.p, 0, ((size_t)n + 1) * sizeof(uint32_t), h->stream));
+        HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->t_ms[3] = elapsed_ms(h->ev[4], h->ev[5]);
+    // ---- host copy for get_roadmap and the breadth-first query
+    h->h_offsets.assign((size_t)n + 1, 0);
+    h->h_nbrs.assign(n_keys, 0);
+    std::vector<double> soa((size_t)h->cfg.dim * n);
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(h->h_offsets.data(), h->offsets.p, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        if (n_keys) HIP_TRY(hipMemcpyAsync(h->h_nbrs.data(), h->nbrs.p, (size_t)n_keys * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpy2DAsync(soa.data(), (size_t)n * sizeof(double), h->ms.p, (size_t)h->args.cap * sizeof(double),
+                                 (size_t)n * sizeof(double), h->cfg.dim, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->h_states.resize((size_t)n * h->cfg.dim);
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t k = 0; k < h->cfg.dim; ++k) h->h_states[(size_t)i * h->cfg.dim + k] = soa[(size_t)k * n + i];
+    h->n = n;
+    h->n_samples = st.n_samples;
+    h->redraw_batches = st.redraw_batches;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_prm_get_sizes(oxhip_prm* h, uint32_t* n_milestones, uint64_t* n_edge_entries, uint64_t* n_samples) {
+    if (!h) return fail(OXHIP_ERR_BAD_ARG, "null handle");
+    if (n_milestones) *n_milestones = h->n;
+    if (n_edge_entries) *n_edge_entries = h->h_nbrs.size();
+    if (n_samples) *n_samples = h->n_samples;
+    return OXHIP_OK;
+}
+
+// get_roadmap (prm.rs:82-84)
+int32_t oxhip_prm_get_roadmap(oxhip_prm* h, double* states, uint32_t cap_nodes, uint64_t* offsets, uint32_t* neighbours,
+                              uint64_t cap_entries) {
+    if (!h) return fail(OXHIP_ERR_BAD_ARG, "null handle");
+    if ((states || offsets) && cap_nodes < h->n) return fail(OXHIP_ERR_CAPACITY, "roadmap buffers too small");
+    if (neighbours && cap_entries < h->h_nbrs.size()) return fail(OXHIP_ERR_CAPACITY, "neighbour buffer too small");
+    if (states && h->n) std::memcpy(states, h->h_states.data(), h->h_states.size() * sizeof(double));
+    if (offsets) {
+        for (uint32_t i = 0; i <= h->n; ++i) offsets[i] = h->h_offsets.empty() ? 0 : h->h_offsets[i];
+    }
+    if (neighbours && !h->h_nbrs.empty()) std::memcpy(neighbours, h->h_nbrs.data(), h->h_nbrs.size() * sizeof(uint32_t));
+    return OXHIP_OK;
+}
+
+// Planner::solve (prm.rs:227-307)
+int32_t oxhip_prm_solve(oxhip_prm* h, double timeout_s, double* path, uint32_t cap_states, uint32_t* len) {
+    if (!h || !len) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    *len = 0;
+    h->start_conn.clear();
+    h->goal_idx.clear();
+    if (!h->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");      // prm.rs:229-236
+    if (h->n == 0) return fail(OXHIP_ERR_UNSAMPLED_STATE_SPACE, "construct_roadmap() left no milestones");  // prm.rs:239-241
+    OX_TRY(select_device(h->cfg.device));
+    const uint32_t n = h->n, dim = h->cfg.dim;
+    HIP_TRY(hipEventRecord(h->ev[0], h->stream));
+    launch_prm_query(h->dp, h->args, n, h->query, h->thr_conn, h->flags.p, h->start_valid.p, h->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev[1], h->stream));
+    std::vector<uint8_t> flags(n);
+    uint32_t start_valid = 0;
+    HIP_TRY(hipMemcpyAsync(flags.data(), h->flags.p, n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(&start_valid, h->start_valid.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->t_ms[4] = elapsed_ms(h->ev[0], h->ev[1]);
+    if (!start_valid) return fail(OXHIP_ERR_INVALID_START_STATE, "start state is in collision");  // prm.rs:243-246
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < n; ++i) {
+        if (flags[i] & 1) h->start_conn.push_back(i);   // prm.rs:249-256
+        if (flags[i] & 2) h->goal_idx.push_back(i);     // prm.rs:259-264
+    }
+    if (h->start_conn.empty() || h->goal_idx.empty())
+        return fail(OXHIP_ERR_NO_SOLUTION_FOUND, "start or goal does not connect to the roadmap");  // prm.rs:266-268
+    // breadth-first search, prm.rs:270-301 (start connections are enqueued twice, as there)
+    std::deque<uint32_t> queue(h->start_conn.begin(), h->start_conn.end());
+    std::vector<int64_t> parent(n, -2);   // parent_map: -2 absent, -1 = Some(None)
+    std::vector<uint8_t> visited(n, 0);
+    for (uint32_t s : h->start_conn) {
+        queue.push_back(s);
+        parent[s] = -1;
+        visited[s] = 1;
+    }
+    const bool has_timeout = timeout_s > 0.0 && std::isfinite(timeout_s);
+    int64_t goal_reached = -1;
+    while (!queue.empty()) {
+        const uint32_t cur = queue.front();
+        queue.pop_front();
+        if (has_timeout && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+            h->t_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            return fail(OXHIP_ERR_TIMEOUT, "graph search timed out");  // prm.rs:285-287
+        }
+        if (flags[cur] & 2) { goal_reached = cur; break; }             // goal_indices.contains(&current_idx)
+        for (uint32_t e = h->h_offsets[cur]; e < h->h_offsets[cur + 1]; ++e) {
+            const uint32_t nb = h->h_nbrs[e];
+            if (!visited[nb]) {
+                visited[nb] = 1;
+                parent[nb] = (int64_t)cur;
+                queue.push_back(nb);
+            }
+        }
+    }
+    h->t_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (goal_reached < 0) return fail(OXHIP_ERR_NO_SOLUTION_FOUND, "goal is not reachable on the roadmap");  // prm.rs:304
+    // reconstruct_path (prm.rs:189-208): [start] ++ (root connection ... goal milestone)
+    std::vector<uint32_t> chain;
+    for (int64_t c = goal_reached; c >= 0; c = parent[(size_t)c]) chain.push_back((uint32_t)c);
+    *len = (uint32_t)chain.size() + 1;
+    if (!path) return OXHIP_OK;
+    if (*len > cap_states) return fail(OXHIP_ERR_CAPACITY, "path buffer too small");
+    std::memcpy(path, h->query.start, dim * sizeof(double));
+    for (size_t j = 0; j < chain.size(); ++j)
+        std::memcpy(path + (j + 1) * dim, h->h_states.data() + (size_t)chain[chain.size() - 1 - j] * dim, dim * sizeof(double));
+    return OXHIP_OK;
+}
+
+int32_t oxhip_prm_get_query_sets(oxhip_prm* h, uint32_t* start_connections, uint32_t cap_start, uint32_t* n_start,
+                                 uint32_t* goal_indices, uint32_t cap_goal, uint32_t* n_goal) {
+    if (!h) return fail(OXHIP_ERR_BAD_ARG, "null handle");
+    if (n_start) *n_start = (uint32_t)h->start_conn.size();
+    if (n_goal) *n_goal = (uint32_t)h->goal_idx.size();
+    if (start_connections) {
+        if (cap_start < h->start_conn.size()) return fail(OXHIP_ERR_CAPACITY, "start_connections buffer too small");
+        if (!h->start_conn.empty()) std::memcpy(start_connections, h->start_conn.data(), h->start_conn.size() * sizeof(uint32_t));
+    }
+    if (goal_indices) {
+        if (cap_goal < h->goal_idx.size()) return fail(OXHIP_ERR_CAPACITY, "goal_indices buffer too small");
+        if (!h->goal_idx.empty()) std::memcpy(goal_indices, h->goal_idx.data(), h->goal_idx.size() * sizeof(uint32_t));
+    }
+    return OXHIP_OK;
+}
+
+int32_t oxhip_prm_last_timing(oxhip_prm* h, double* phase_ms, uint64_t* n_candidates, uint32_t* redraw_batches) {
+    if (!h) return fail(OXHIP_ERR_BAD_ARG, "null handle");
+    if (phase_ms) for (int i = 0; i < 6; ++i) phase_ms[i] = h->t_ms[i];
+    if (n_candidates) *n_candidates = h->n_candidates;
+    if (redraw_batches) *redraw_batches = h->redraw_batches;
+    return OXHIP_OK;
+}
+
+}  // extern "C"

@@ -27,6 +27,7 @@ def test_header_and_binding_export_the_same_symbols(L):
         assert hasattr(L, name), name
     assert L.oxhip_abi_version() == 1
     assert C.sizeof(capi.Config) == 200  # layout of oxhip_rrt_config on the ABI
+    assert C.sizeof(capi.PrmConfig) == 192  # oxhip_prm_config
 
 
 def test_status_strings_cover_planning_error(L):
@@ -130,3 +131,33 @@ def test_null_and_range_arguments_are_bad_arg_not_crashes(L):
     with pytest.raises(capi.OxhipError) as ei:   # RRTConnect has no resident kernel
         capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.1, 0.0, 1, 10, kernel=capi.KERNEL_RESIDENT, planner=capi.PLANNER_RRT_CONNECT)
     assert ei.value.status == capi.ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("kw,code", [
+    (dict(dim=0, bounds=[]), capi.ERR_BAD_ARG),
+    (dict(bounds=[(0.0, math.inf), (0.0, 1.0)]), capi.ERR_UNBOUNDED),    # rvss.rs:239-241
+    (dict(bounds=[(1.0, 1.0), (0.0, 1.0)]), capi.ERR_ZERO_VOLUME),       # rvss.rs:78-83,242-244
+    (dict(max_milestones=0), capi.ERR_BAD_ARG),
+    (dict(connection_radius=float("nan")), capi.ERR_BAD_ARG),
+    (dict(lvs_fraction=0.0), capi.ERR_BAD_ARG),                          # check_motion would never end
+    (dict(connection_radius=1e9), capi.ERR_BAD_ARG),                     # > 1e6 validity checks per edge
+    (dict(), capi.ERR_NO_DEVICE),                                        # valid arguments: only the GPU is missing
+])
+def test_prm_create_validates_like_the_reference(L, kw, code):
+    import torch
+    if code == capi.ERR_NO_DEVICE and torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    args = dict(dim=2, bounds=[(0.0, 10.0)] * 2, connection_radius=0.5, max_milestones=100)
+    args.update(kw)
+    with pytest.raises(capi.OxhipError) as ei:
+        capi.PRMRoadmap(**args)
+    assert ei.value.status == code
+
+
+def test_prm_null_arguments_are_rejected(L):
+    assert L.oxhip_prm_create(None, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_prm_destroy(None) == capi.OK
+    for fn in (L.oxhip_prm_construct_roadmap,):
+        assert fn(None) == capi.ERR_BAD_ARG
+    assert L.oxhip_prm_solve(None, 0.0, None, 0, None) == capi.ERR_BAD_ARG
+    assert L.oxhip_prm_get_sizes(None, None, None, None) == capi.ERR_BAD_ARG
