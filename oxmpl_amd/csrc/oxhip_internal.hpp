@@ -47,7 +47,7 @@ struct PrmState {            // persists in HBM between launches
     uint32_t pad;
 };
 struct PrmArgs {
-    double* ms;              // milestones, SoA [dim][cap]
+    double* ms;              // milestones, AoS [cap][dim] (the i side of the pair search is read by scalar loads)
     uint32_t cap;
     uint32_t n_target;       // sample until the roadmap holds this many milestones ...
     uint64_t max_samples;    // ... or this many samples were drawn

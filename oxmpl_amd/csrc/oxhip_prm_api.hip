@@ -312,17 +312,13 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
     // ---- host copy for get_roadmap and the breadth-first query
     h->h_offsets.assign((size_t)n + 1, 0);
     h->h_nbrs.assign(n_keys, 0);
-    std::vector<double> soa((size_t)h->cfg.dim * n);
+    h->h_states.assign((size_t)n * h->cfg.dim, 0.0);
     if (n) {
         HIP_TRY(hipMemcpyAsync(h->h_offsets.data(), h->offsets.p, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
         if (n_keys) HIP_TRY(hipMemcpyAsync(h->h_nbrs.data(), h->nbrs.p, (size_t)n_keys * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpy2DAsync(soa.data(), (size_t)n * sizeof(double), h->ms.p, (size_t)h->args.cap * sizeof(double),
-                                 (size_t)n * sizeof(double), h->cfg.dim, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_states.data(), h->ms.p, (size_t)n * h->cfg.dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    h->h_states.resize((size_t)n * h->cfg.dim);
-    for (uint32_t i = 0; i < n; ++i)
-        for (uint32_t k = 0; k < h->cfg.dim; ++k) h->h_states[(size_t)i * h->cfg.dim + k] = soa[(size_t)k * n + i];
     h->n = n;
     h->n_samples = st.n_samples;
     h->redraw_batches = st.redraw_batches;

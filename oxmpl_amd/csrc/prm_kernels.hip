@@ -11,8 +11,9 @@
 // is { (j, i) : i < j, distance < r, check_motion(m_j -> m_i) }, every node's `edges` list ending up in
 // ascending order.  That makes construction three data-parallel phases:
 //   1. prm_sample_kernel   ordered compaction of the valid samples of the ChaCha12 stream
-//   2. prm_pairs_kernel    all pairs (j, i<j): LDS-staged i tiles, 4 register-resident j per thread,
-//                          f64 VALU bound (3*dim-1 flops + 1 compare per pair); emits the sparse candidates
+//   2. prm_pairs_kernel    all pairs (j, i<j): 4 register-resident j per thread, the i side streamed through
+//                          the scalar cache as VALU scalar operands; f64 VALU bound (3*dim-1 flops + 1 compare
+//                          per pair); emits the sparse candidates
 //   3. prm_edge_kernel     check_motion(m_j -> m_i) per candidate; emits both directed keys (u<<32 | v)
 // followed by one radix sort of the keys (rocPRIM) and a CSR extraction, which yields each node's
 // neighbours in ascending order -- exactly the reference's `edges` vectors.
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(kSampleBatch) void prm_sample_kernel(DevParams p, P
         const bool keep = valid && n + rank < a.n_target;
         if (keep) {
 #pragma unroll
-            for (int k = 0; k < DIM; ++k) a.ms[(size_t)k * a.cap + n + rank] = q[k];
+            for (int k = 0; k < DIM; ++k) a.ms[(size_t)(n + rank) * DIM + k] = q[k];
             if (n + rank == a.n_target - 1) sh_last = tid;  // the sample that completes the roadmap
         }
         __syncthreads();
@@ -193,13 +194,67 @@ __global__ __launch_bounds__(kSampleBatch) void prm_sample_kernel(DevParams p, P
 constexpr int kPairThreads = 256;
 constexpr int kPairR = 4;                           // milestones j held in registers per thread
 constexpr int kPairJB = kPairThreads * kPairR;      // j per workgroup
-constexpr int kPairIC = 1024;                       // i per workgroup (staged 256 at a time)
-constexpr int kPairTile = 256;
+constexpr int kPairIC = 1024;                       // i per workgroup
+
+constexpr int kStage = 512;                         // per-wave LDS staging of hits before they go to HBM
+
+// Hits are appended to a per-wave LDS buffer with ballot / prefix-count positions (the wave is its only
+// writer, so no atomic is involved) and flushed to the candidate list with ONE global atomic per flush.
+// A single global counter bumped once per hit serialises at the L2: 291 k hits cost 3 ms that way.
+struct PairStage {
+    uint2* buf;       // this wave's kStage entries in LDS
+    uint32_t cnt;     // wave-uniform
+};
+
+__device__ __forceinline__ void stage_flush(const PrmArgs& a, PairStage& st, uint32_t lane) {
+    if (st.cnt == 0) return;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&a.state->n_cand, (unsigned long long)st.cnt);
+    base = uni64(base);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave's LDS writes precede its reads below
+    for (uint32_t e = lane; e < st.cnt; e += 64) {
+        const unsigned long long slot = base + e;
+        if (slot < (unsigned long long)a.cand_cap) a.cand[slot] = st.buf[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and those reads precede the next writes
+    st.cnt = 0;
+}
+
+// One i against the thread's kPairR milestones.  `ci` is wave-uniform: it is loaded through the scalar
+// cache (s_load) and feeds the f64 VALU as a scalar operand, so the inner loop touches neither LDS nor
+// the vector memory path.  Hits are rare (a few 1e-4 of all pairs): one wave-uniform branch per i.
+template <int DIM, bool DIAG>
+__device__ __forceinline__ void pairs_one_i(const PrmArgs& a, PairStage& st, uint32_t lane, const double (&cj)[kPairR][DIM],
+                                            const uint32_t (&jr)[kPairR], const double* __restrict__ ms, uint32_t i,
+                                            double thr) {
+    double ci[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) ci[k] = ms[(size_t)i * DIM + k];
+    bool h[kPairR];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < kPairR; ++r) {
+        const double d2 = dist2<DIM>(cj[r], ci, DIM);   // distance(q_rand, other)^2, rvss.rs:137-155
+        h[r] = d2 <= thr;                                 // sqrt(d2) < connection_radius, exactly
+        if (DIAG) h[r] = h[r] && i < jr[r];
+        any = any || h[r];
+    }
+    if (__ballot(any) != 0) {
+#pragma unroll
+        for (int r = 0; r < kPairR; ++r) {
+            const uint64_t m = __ballot(h[r]);
+            if (h[r]) st.buf[st.cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2(jr[r], i);
+            st.cnt += (uint32_t)__popcll(m);
+        }
+        if (st.cnt > (uint32_t)(kStage - 64 * kPairR)) stage_flush(a, st, lane);  // room for one more full i
+    }
+}
 
 template <int DIM>
-__global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, uint32_t j0, uint32_t j1, double thr) {
-    __shared__ double tile[kPairTile][DIM];
-    const uint32_t tid = threadIdx.x;
+__global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, const double* __restrict__ ms, uint32_t j0,
+                                                                  uint32_t j1, double thr) {
+    __shared__ uint2 stage[kPairThreads / 64][kStage];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t jb0 = j0 + blockIdx.y * kPairJB;                 // first j of this block
     const uint32_t jb1 = jb0 + kPairJB < j1 ? jb0 + kPairJB : j1;   // one past its last j
     const uint32_t i_lo = blockIdx.x * kPairIC;
@@ -212,35 +267,14 @@ __global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, uint
     for (int r = 0; r < kPairR; ++r) {
         jr[r] = jb0 + r * kPairThreads + tid;
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) cj[r][k] = jr[r] < jb1 ? a.ms[(size_t)k * a.cap + jr[r]] : __builtin_inf();
+        for (int k = 0; k < DIM; ++k) cj[r][k] = jr[r] < jb1 ? ms[(size_t)jr[r] * DIM + k] : __builtin_inf();
     }
-    for (uint32_t sub = i_lo; sub < i_hi; sub += kPairTile) {
-        const uint32_t cnt = i_hi - sub < (uint32_t)kPairTile ? i_hi - sub : (uint32_t)kPairTile;
-        __syncthreads();
-        if (tid < cnt) {
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) tile[tid][k] = a.ms[(size_t)k * a.cap + sub + tid];
-        }
-        __syncthreads();
-        const bool diag = sub + cnt > jb0;  // some i of this tile is not below every j of the block
-#pragma unroll 2
-        for (uint32_t ii = 0; ii < cnt; ++ii) {
-            double ci[DIM];
-#pragma unroll
-            for (int k = 0; k < DIM; ++k) ci[k] = tile[ii][k];   // wave-uniform address: LDS broadcast
-            const uint32_t i = sub + ii;
-#pragma unroll
-            for (int r = 0; r < kPairR; ++r) {
-                const double d2 = dist2<DIM>(cj[r], ci, DIM);       // distance(q_rand, other)^2, rvss.rs:137-155
-                bool hit = d2 <= thr;                                // sqrt(d2) < connection_radius, exactly
-                if (diag) hit = hit && i < jr[r];
-                if (hit) {
-                    const unsigned long long slot = atomicAdd(&a.state->n_cand, 1ull);
-                    if (slot < (unsigned long long)a.cand_cap) a.cand[slot] = make_uint2(jr[r], i);
-                }
-            }
-        }
-    }
+    PairStage st{stage[tid >> 6], 0u};
+    // i below every j of the block: no index test; the rest of the range (the diagonal blocks) tests i < j
+    const uint32_t i_mid = i_hi < jb0 ? i_hi : (i_lo > jb0 ? i_lo : jb0);
+    for (uint32_t i = i_lo; i < i_mid; ++i) pairs_one_i<DIM, false>(a, st, lane, cj, jr, ms, i, thr);
+    for (uint32_t i = i_mid; i < i_hi; ++i) pairs_one_i<DIM, true>(a, st, lane, cj, jr, ms, i, thr);
+    stage_flush(a, st, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,8 +288,8 @@ __global__ __launch_bounds__(256) void prm_edge_kernel(DevParams p, PrmArgs a, u
     double from[DIM], to[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
-        from[k] = a.ms[(size_t)k * a.cap + pr.x];
-        to[k] = a.ms[(size_t)k * a.cap + pr.y];
+        from[k] = a.ms[(size_t)pr.x * DIM + k];
+        to[k] = a.ms[(size_t)pr.y * DIM + k];
     }
     if (!motion_valid_seq<DIM>(p, from, to)) return;
     const uint32_t slot = atomicAdd(&a.state->n_keys, 2u);
@@ -293,7 +327,7 @@ __global__ __launch_bounds__(256) void prm_query_kernel(DevParams p, PrmArgs a, 
     if (i >= n) return;
     double m[DIM];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) m[k] = a.ms[(size_t)k * a.cap + i];
+    for (int k = 0; k < DIM; ++k) m[k] = a.ms[(size_t)i * DIM + k];
     uint8_t f = 0;
     if (dist2<DIM>(s, m, DIM) <= thr && motion_valid_seq<DIM>(p, s, m)) f |= 1;   // prm.rs:251-252
     if (dist2<DIM>(m, g, DIM) <= q.goal_thr) f |= 2;                               // goal.is_satisfied, prm.rs:261
@@ -330,7 +364,8 @@ void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_
     const uint32_t ichunks = (j1 - 1 + kPairIC - 1) / kPairIC;
     dim_dispatch(p.dim, [&](auto d) {
         constexpr int D = decltype(d)::value;
-        hipLaunchKernelGGL(prm_pairs_kernel<D>, dim3(ichunks, jblocks), dim3(kPairThreads), 0, s, a, j0, j1, thr);
+        hipLaunchKernelGGL(prm_pairs_kernel<D>, dim3(ichunks, jblocks), dim3(kPairThreads), 0, s, a, (const double*)a.ms, j0,
+                           j1, thr);
     });
 }
 

@@ -4,6 +4,8 @@ config 1: README quick-start, R^2, disc obstacle r=2 at the origin, start (-5,-5
           (/root/reference README.md:147-171, oxmpl-js/examples/simple_2d_planning.js:8-41)
 wall    : the reference's own RRT test scene (oxmpl/tests/rrt_rvss_tests.rs:109-159)
 config 2: R^3, [0,10]^3, 64 random spheres, start (.5,.5,.5), goal ball (9.5,9.5,9.5) r=0.5
+config 5: PRM (BASELINE.json configs[4]): R^6, [0,10]^6, 32 random hyperspheres, 50,000 milestones,
+          connection radius 2.0, start (1,..,1), goal ball (9,..,9) r=1.5
 """
 import struct
 
@@ -66,6 +68,27 @@ def config2():
     return dict(dim=3, bounds=[(0.0, 10.0)] * 3, max_distance=0.5, goal_bias=0.05, lvs_fraction=0.05,
                 start=start, goal_centre=goal, goal_radius=0.5,
                 spheres=sphere_field(keep_clear=[start, goal]), boxes=None)
+
+
+def config5():
+    start, goal = [1.0] * 6, [9.0] * 6
+    return dict(dim=6, bounds=[(0.0, 10.0)] * 6, connection_radius=2.0, lvs_fraction=0.05, max_milestones=50000,
+                start=start, goal_centre=goal, goal_radius=1.5,
+                spheres=sphere_field(seed=0x5EED0005, n=32, dim=6, lo=1.0, hi=9.0, rmin=2.0, rmax=3.5,
+                                     keep_clear=[start, goal]), boxes=None)
+
+
+def make_prm(sc, max_milestones=None, seed=42, stream=0, device=0, timeout=0.0, connection_radius=None):
+    """Build a PRMRoadmap for a scenario dict and run Planner::setup."""
+    from .capi import PRMRoadmap
+    g = PRMRoadmap(sc["dim"], sc["bounds"], connection_radius or sc["connection_radius"],
+                   max_milestones or sc["max_milestones"], timeout, sc["lvs_fraction"], 0, seed, stream, device)
+    if sc["spheres"] is not None:
+        g.set_spheres(*sc["spheres"])
+    if sc["boxes"] is not None:
+        g.set_boxes(*sc["boxes"])
+    g.setup(sc["start"], sc["goal_centre"], sc["goal_radius"])
+    return g
 
 
 def make_batch(sc, n_problems, max_nodes=10000, stop_at_goal=True, seed=42, first_problem_id=0, device=0, kernel=0,
