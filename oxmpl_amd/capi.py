@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_PKG, "lib", "liboxmpl_hip.so")
+# OXMPL_HIP_LIB: development override (kernel tuning experiments load alternative builds)
+_LIB = os.environ.get("OXMPL_HIP_LIB") or os.path.join(_PKG, "lib", "liboxmpl_hip.so")
 
 MAX_DIM = 8
 OK, ERR_TIMEOUT, ERR_NO_SOLUTION_FOUND, ERR_PLANNER_UNINITIALISED = 0, 1, 2, 3

@@ -55,20 +55,32 @@ struct PrmArgs {
     PrmState* state;
     uint2* cand;             // (j, i) with i < j and distance < connection_radius
     uint32_t cand_cap;
-    uint64_t* keys;          // (u << 32) | v for every directed edge u -> v
+    uint64_t* keys;          // (u << shift) | v for every directed edge u -> v, shift = bits of (cap - 1)
+};
+struct PrmSpec {              // one round of the parallel sampler
+    uint64_t pos0;           // stream word of the round's first sample (= PrmState::draws)
+    uint32_t m;              // samples drawn this round
+    uint32_t pad;
+    double* tmp;             // [m][dim] the round's samples
+    uint64_t* vbits;         // [ceil(m/64)] validity ballots
+    uint32_t* wave_off;      // [ceil(m/64)] per-wave valid counts, then their exclusive prefix
+    uint32_t* redraw_flag;   // set when rand's range sampler would have rejected a draw: the round is replayed
+    PrmState* result;        // the state after this round (valid when redraw_flag stays 0)
 };
 struct PrmQuery {
     double start[8], goal_c[8];
     double goal_thr;         // satisfied iff d2 <= goal_thr
 };
 void launch_prm_sample(const DevParams& p, const PrmArgs& a, hipStream_t s);
+// speculative parallel round: draws, scans, compacts; the host commits sp.result when no draw was rejected
+void launch_prm_sample_spec(const DevParams& p, const PrmArgs& a, const PrmSpec& sp, uint32_t n0, hipStream_t s);
 void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_t j1, double thr, hipStream_t s);
 void launch_prm_edges(const DevParams& p, const PrmArgs& a, uint32_t n_cand, hipStream_t s);
 // rocPRIM radix sort of the directed keys; tmp == nullptr queries tmp_bytes
-hipError_t prm_sort_keys(void* tmp, size_t& tmp_bytes, uint64_t* in, uint64_t* out, uint32_t n_keys, uint32_t n_nodes,
+hipError_t prm_sort_keys(void* tmp, size_t& tmp_bytes, uint64_t* in, uint64_t* out, uint32_t n_keys, uint32_t cap,
                          hipStream_t s);
-void launch_prm_csr(const uint64_t* sorted, uint32_t n_keys, uint32_t n_nodes, uint32_t* offsets, uint32_t* nbrs,
-                    hipStream_t s);
+void launch_prm_csr(const uint64_t* sorted, uint32_t n_keys, uint32_t n_nodes, uint32_t cap, uint32_t* offsets,
+                    uint32_t* nbrs, hipStream_t s);
 void launch_prm_query(const DevParams& p, const PrmArgs& a, uint32_t n, const PrmQuery& q, double thr, uint8_t* flags,
                       uint32_t* start_valid, hipStream_t s);
 

@@ -27,8 +27,16 @@ struct oxhip_prm {
     DevBuf<PrmState> state;
     DevBuf<uint2> cand;
     DevBuf<uint64_t> keys, keys_sorted;
+    DevBuf<uint8_t> sort_tmp;
+    uint32_t n_keys = 0;       // directed edge entries of the constructed roadmap
+    bool host_copy = false;    // h_offsets / h_nbrs / h_states are current
     DevBuf<uint32_t> offsets, nbrs, start_valid;
     DevBuf<uint8_t> flags;
+    // parallel sampler scratch (one round)
+    DevBuf<double> spec_tmp;
+    DevBuf<uint64_t> spec_vbits;
+    DevBuf<uint32_t> spec_off, spec_flag;
+    double valid_rate = 1.0;   // running estimate of P(sample is valid), sizes the rounds
     bool is_setup = false;
     PrmQuery query{};
     // host copy of the constructed roadmap
@@ -72,6 +80,8 @@ int32_t set_query(oxhip_prm* h, const double* start, const double* goal_centre, 
 
 void clear_roadmap(oxhip_prm* h) {
     h->n = 0;
+    h->n_keys = 0;
+    h->host_copy = false;
     h->n_samples = 0;
     h->redraw_batches = 0;
     h->h_offsets.clear();
@@ -79,6 +89,66 @@ void clear_roadmap(oxhip_prm* h) {
     h->h_states.clear();
     h->start_conn.clear();
     h->goal_idx.clear();
+}
+
+// Draw samples until `target` milestones exist or `max_samples` were drawn.  Rounds of the parallel sampler
+// sized by the observed validity rate; a round in which rand's range sampler would have rejected a draw is
+// replayed by the sequential kernel (exact for any bounds, and about as likely as a 2^-52 event).
+int32_t sample_until(oxhip_prm* h, PrmState& st, uint32_t target, uint64_t max_samples) {
+    constexpr uint64_t kRoundMax = 1ull << 22;
+    const uint32_t dim = h->cfg.dim;
+    h->args.n_target = target;
+    while (st.n_milestones < target && st.n_samples < max_samples) {
+        const uint32_t need = target - st.n_milestones;
+        uint64_t want = (uint64_t)((double)need / h->valid_rate * 1.02) + 256;
+        want = std::min(want, std::min(max_samples - st.n_samples, kRoundMax));
+        const uint32_t m = (uint32_t)want, nw = (m + 63) / 64;
+        if (h->spec_tmp.n < (size_t)m * dim) HIP_TRY(h->spec_tmp.alloc((size_t)m * dim));
+        if (h->spec_vbits.n < nw) { HIP_TRY(h->spec_vbits.alloc(nw)); HIP_TRY(h->spec_off.alloc(nw)); }
+        if (h->spec_flag.n == 0) HIP_TRY(h->spec_flag.alloc(1));
+        HIP_TRY(hipMemsetAsync(h->spec_flag.p, 0, sizeof(uint32_t), h->stream));
+        PrmSpec sp{};
+        sp.pos0 = st.draws; sp.m = m;
+        sp.tmp = h->spec_tmp.p; sp.vbits = h->spec_vbits.p; sp.wave_off = h->spec_off.p;
+        sp.redraw_flag = h->spec_flag.p; sp.result = h->state.p;   // the scan kernel advances the device state
+        launch_prm_sample_spec(h->dp, h->args, sp, st.n_milestones, h->stream);
+        HIP_TRY(hipGetLastError());
+        PrmState after{};
+        uint32_t flag = 0;
+        HIP_TRY(hipMemcpyAsync(&after, h->state.p, sizeof(PrmState), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(&flag, h->spec_flag.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (flag == 0) {
+            const double drawn = (double)(after.n_samples - st.n_samples), got = (double)(after.n_milestones - st.n_milestones);
+            h->valid_rate = std::max(1.0 / 64.0, std::min(1.0, (got + 1.0) / (drawn + 1.0)));
+            st = after;
+        } else {
+            // a draw was rejected somewhere in the round: put the state back and replay this window in order
+            OX_TRY(write_state(h, st));
+            h->args.max_samples = st.n_samples + m;
+            launch_prm_sample(h->dp, h->args, h->stream);
+            HIP_TRY(hipGetLastError());
+            OX_TRY(read_state(h, st));
+        }
+    }
+    return OXHIP_OK;
+}
+
+// host copy of the roadmap for get_roadmap and the breadth-first query (once per construction)
+int32_t fetch_roadmap(oxhip_prm* h) {
+    if (h->host_copy) return OXHIP_OK;
+    const uint32_t n = h->n, n_keys = h->n_keys;
+    h->h_offsets.assign((size_t)n + 1, 0);
+    h->h_nbrs.assign(n_keys, 0);
+    h->h_states.assign((size_t)n * h->cfg.dim, 0.0);
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(h->h_offsets.data(), h->offsets.p, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        if (n_keys) HIP_TRY(hipMemcpyAsync(h->h_nbrs.data(), h->nbrs.p, (size_t)n_keys * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->h_states.data(), h->ms.p, (size_t)n * h->cfg.dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->host_copy = true;
+    return OXHIP_OK;
 }
 
 double elapsed_ms(hipEvent_t a, hipEvent_t b) {
@@ -219,19 +289,17 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
     h->n_candidates = 0;
     PrmState st{};
     OX_TRY(write_state(h, st));
+    h->valid_rate = 1.0;
     // without a wall clock the roadmap is built in one round; with one, in doubling rounds with the
     // clock read in between (the reference reads it before every sample, prm.rs:118)
     uint32_t target = has_timeout ? std::min<uint32_t>(n_max, 4096u) : n_max;
     uint32_t n_done = 0;  // milestones whose pairs are already connected
     for (;;) {
         // ---- 1. sample until `target` milestones
-        h->args.n_target = target;
-        h->args.max_samples = max_samples;
         HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-        launch_prm_sample(h->dp, h->args, h->stream);
-        HIP_TRY(hipGetLastError());
+        OX_TRY(sample_until(h, st, target, max_samples));
         HIP_TRY(hipEventRecord(h->ev[1], h->stream));
-        OX_TRY(read_state(h, st));
+        HIP_TRY(hipStreamSynchronize(h->stream));
         h->t_ms[0] += elapsed_ms(h->ev[0], h->ev[1]);
         const uint32_t n_now = st.n_milestones;
         // ---- 2. pairs (j in [n_done, n_now), i < j) within the connection radius
@@ -290,35 +358,26 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
     }
     // ---- 4. sort the directed keys -> every node's neighbours in ascending order (the reference's `edges`)
     const uint32_t n = st.n_milestones, n_keys = st.n_keys;
+    size_t tmp_bytes = 0;
+    if (n_keys) {
+        // (re)size the sort's buffers before the timed region: hipMalloc is a blocking call
+        if (h->keys_sorted.n < n_keys) { HIP_TRY(h->keys_sorted.alloc(n_keys)); HIP_TRY(h->nbrs.alloc(n_keys)); }
+        HIP_TRY(prm_sort_keys(nullptr, tmp_bytes, h->keys.p, h->keys_sorted.p, n_keys, h->args.cap, h->stream));
+        if (h->sort_tmp.n < tmp_bytes) HIP_TRY(h->sort_tmp.alloc(tmp_bytes));
+    }
     HIP_TRY(hipEventRecord(h->ev[4], h->stream));
     if (n_keys) {
-        HIP_TRY(h->keys_sorted.alloc(n_keys));
-        HIP_TRY(h->nbrs.alloc(n_keys));
-        size_t tmp_bytes = 0;
-        HIP_TRY(prm_sort_keys(nullptr, tmp_bytes, h->keys.p, h->keys_sorted.p, n_keys, n, h->stream));
-        DevBuf<uint8_t> tmp;
-        HIP_TRY(tmp.alloc(tmp_bytes ? tmp_bytes : 1));
-        HIP_TRY(prm_sort_keys(tmp.p, tmp_bytes, h->keys.p, h->keys_sorted.p, n_keys, n, h->stream));
-        launch_prm_csr(h->keys_sorted.p, n_keys, n, h->offsets.p, h->nbrs.p, h->stream);
+        HIP_TRY(prm_sort_keys(h->sort_tmp.p, tmp_bytes, h->keys.p, h->keys_sorted.p, n_keys, h->args.cap, h->stream));
+        launch_prm_csr(h->keys_sorted.p, n_keys, n, h->args.cap, h->offsets.p, h->nbrs.p, h->stream);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(h->ev[5], h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));  // tmp is freed at scope exit
     } else {
         HIP_TRY(hipMemsetAsync(h->offsets.p, 0, ((size_t)n + 1) * sizeof(uint32_t), h->stream));
-        HIP_TRY(hipEventRecord(h->ev[5], h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    HIP_TRY(hipEventRecord(h->ev[5], h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     h->t_ms[3] = elapsed_ms(h->ev[4], h->ev[5]);
-    // ---- host copy for get_roadmap and the breadth-first query
-    h->h_offsets.assign((size_t)n + 1, 0);
-    h->h_nbrs.assign(n_keys, 0);
-    h->h_states.assign((size_t)n * h->cfg.dim, 0.0);
-    if (n) {
-        HIP_TRY(hipMemcpyAsync(h->h_offsets.data(), h->offsets.p, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        if (n_keys) HIP_TRY(hipMemcpyAsync(h->h_nbrs.data(), h->nbrs.p, (size_t)n_keys * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->h_states.data(), h->ms.p, (size_t)n * h->cfg.dim * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-    }
+    h->n_keys = n_keys;
+    h->host_copy = false;   // fetched by the first get_roadmap / solve
     h->n = n;
     h->n_samples = st.n_samples;
     h->redraw_batches = st.redraw_batches;
@@ -328,7 +387,7 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
 int32_t oxhip_prm_get_sizes(oxhip_prm* h, uint32_t* n_milestones, uint64_t* n_edge_entries, uint64_t* n_samples) {
     if (!h) return fail(OXHIP_ERR_BAD_ARG, "null handle");
     if (n_milestones) *n_milestones = h->n;
-    if (n_edge_entries) *n_edge_entries = h->h_nbrs.size();
+    if (n_edge_entries) *n_edge_entries = h->n_keys;
     if (n_samples) *n_samples = h->n_samples;
     return OXHIP_OK;
 }
@@ -337,6 +396,10 @@ int32_t oxhip_prm_get_sizes(oxhip_prm* h, uint32_t* n_milestones, uint64_t* n_ed
 int32_t oxhip_prm_get_roadmap(oxhip_prm* h, double* states, uint32_t cap_nodes, uint64_t* offsets, uint32_t* neighbours,
                               uint64_t cap_entries) {
     if (!h) return fail(OXHIP_ERR_BAD_ARG, "null handle");
+    if (h->n) {
+        OX_TRY(select_device(h->cfg.device));
+        OX_TRY(fetch_roadmap(h));
+    }
     if ((states || offsets) && cap_nodes < h->n) return fail(OXHIP_ERR_CAPACITY, "roadmap buffers too small");
     if (neighbours && cap_entries < h->h_nbrs.size()) return fail(OXHIP_ERR_CAPACITY, "neighbour buffer too small");
     if (states && h->n) std::memcpy(states, h->h_states.data(), h->h_states.size() * sizeof(double));
@@ -356,6 +419,7 @@ int32_t oxhip_prm_solve(oxhip_prm* h, double timeout_s, double* path, uint32_t c
     if (!h->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");      // prm.rs:229-236
     if (h->n == 0) return fail(OXHIP_ERR_UNSAMPLED_STATE_SPACE, "construct_roadmap() left no milestones");  // prm.rs:239-241
     OX_TRY(select_device(h->cfg.device));
+    OX_TRY(fetch_roadmap(h));
     const uint32_t n = h->n, dim = h->cfg.dim;
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
     launch_prm_query(h->dp, h->args, n, h->query, h->thr_conn, h->flags.p, h->start_valid.p, h->stream);

@@ -188,13 +188,134 @@ __global__ __launch_bounds__(kSampleBatch) void prm_sample_kernel(DevParams p, P
     }
 }
 
+// ---- the parallel sampler.  A rejected draw is a ~2^-52 event per coordinate, so a round of M samples is
+// first drawn as if none happens: sample s sits at stream word pos0 + s * DIM.  Any rejection anywhere
+// in the round raises a flag and the host replays that round with the sequential kernel above.
+constexpr int kSpecThreads = 256;
+
+template <int DIM>
+__global__ __launch_bounds__(kSpecThreads) void prm_sample_spec_kernel(DevParams p, PrmArgs a, PrmSpec sp) {
+    constexpr int kBlocks = kSpecThreads * DIM / 8 + 2;
+    __shared__ uint32_t wbuf[kBlocks][16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t s0 = blockIdx.x * kSpecThreads;           // first sample of this workgroup (round-relative)
+    const uint64_t w0 = sp.pos0 + (uint64_t)s0 * DIM;        // its first stream word
+    const uint64_t blk0 = w0 >> 3;
+    for (uint32_t b = tid; b < (uint32_t)kBlocks; b += kSpecThreads) {
+        uint32_t o[16];
+        chacha12_block(p.seed, blk0 + b, a.stream, o);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) wbuf[b][w] = o[w];
+    }
+    __syncthreads();
+    const uint32_t s = s0 + tid;
+    const bool act = s < sp.m;
+    double q[DIM];
+    bool redraw = false;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const uint32_t rel = (uint32_t)(w0 - (blk0 << 3)) + tid * DIM + k;   // < kBlocks * 8
+        const uint64_t word = ((uint64_t)wbuf[rel >> 3][(rel & 7) * 2 + 1] << 32) | wbuf[rel >> 3][(rel & 7) * 2];
+        const uint64_t bits = (word >> 12) | 0x3FF0000000000000ull;
+        const double v01 = __longlong_as_double((long long)bits) - 1.0;
+        double res = v01 * p.scale[k];
+        res = res + p.lo[k];
+        redraw = redraw || !(res < p.hi[k]);
+        q[k] = res;
+    }
+    if (__ballot(act && redraw) != 0 && lane == 0) atomicOr(sp.redraw_flag, 1u);
+    const bool valid = act && state_valid_seq<DIM>(p, q);                      // prm.rs:123
+    const uint64_t bal = __ballot(valid);
+    if (valid) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) sp.tmp[(size_t)s * DIM + k] = q[k];
+    }
+    if (lane == 0) {
+        sp.vbits[s >> 6] = bal;
+        sp.wave_off[s >> 6] = (uint32_t)__popcll(bal);    // counts now, exclusive offsets after the scan kernel
+    }
+}
+
+// one workgroup: exclusive scan of the per-wave counts, the sample that completes the roadmap, the new state
+__global__ __launch_bounds__(1024) void prm_sample_scan_kernel(PrmArgs a, PrmSpec sp, uint32_t dim) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t sh_consumed;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nw = (sp.m + 63) >> 6;
+    const uint32_t per = (nw + 1023) / 1024;
+    const uint32_t b = tid * per, e = b + per < nw ? b + per : nw;
+    uint32_t mine = 0;
+    for (uint32_t w = b; w < e; ++w) mine += sp.wave_off[w];
+    // inclusive scan across the workgroup
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(inc, off, 64);
+        if ((int)lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    if (tid == 0) sh_consumed = sp.m;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        base += (uint32_t)w < wave ? wsum[w] : 0u;
+        total += wsum[w];
+    }
+    uint32_t run = base + inc - mine;   // exclusive prefix of this thread's first wave
+    const PrmState st = *a.state;
+    const uint32_t need = a.n_target - st.n_milestones;   // > 0: the host only launches an incomplete round
+    for (uint32_t w = b; w < e; ++w) {
+        const uint32_t c = sp.wave_off[w];
+        sp.wave_off[w] = run;
+        if (run < need && run + c >= need) {
+            // the (need - run)-th valid sample of this wave completes the roadmap: nothing after it is drawn
+            uint64_t bits = sp.vbits[w];
+            for (uint32_t k = 1; k < need - run; ++k) bits &= bits - 1;
+            sh_consumed = w * 64 + (uint32_t)(__ffsll((unsigned long long)bits) - 1) + 1;
+        }
+        run += c;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        PrmState ns = st;
+        const uint32_t consumed = sh_consumed;
+        ns.n_milestones = total >= need ? a.n_target : st.n_milestones + total;
+        ns.n_samples = st.n_samples + consumed;
+        ns.draws = st.draws + (uint64_t)consumed * dim;
+        sp.result[0] = ns;            // committed by the host only when no draw of the round was rejected
+    }
+}
+
+// ordered compaction of the round's valid samples behind the existing milestones
+template <int DIM>
+__global__ __launch_bounds__(kSpecThreads) void prm_sample_compact_kernel(PrmArgs a, PrmSpec sp, uint32_t n0) {
+    const uint32_t s = blockIdx.x * kSpecThreads + threadIdx.x, lane = threadIdx.x & 63;
+    if (s >= sp.m) return;
+    const uint64_t bal = sp.vbits[s >> 6];
+    if (!((bal >> lane) & 1ull)) return;
+    const uint32_t dst = n0 + sp.wave_off[s >> 6] + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (dst >= a.n_target) return;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) a.ms[(size_t)dst * DIM + k] = sp.tmp[(size_t)s * DIM + k];
+}
+
 // ------------------------------------------------------------------------------------------------
 // 2. all pairs within the connection radius
 
 constexpr int kPairThreads = 256;
-constexpr int kPairR = 4;                           // milestones j held in registers per thread
+#ifndef OXHIP_PAIR_R
+#define OXHIP_PAIR_R 2
+#endif
+#ifndef OXHIP_PAIR_IC
+#define OXHIP_PAIR_IC 256
+#endif
+// Tile shape (j per thread, i per workgroup), measured at 50,000 milestones in R^6 on one MI355X:
+// (4,2048) 1.32 ms, (4,1024) 0.87, (4,512) 0.81, (4,256) 0.79, (4,128) 0.76, (2,512) 0.77, (2,256) 0.75 --
+// the triangular grid wants many small workgroups; 0.75 ms is the chip's sustained f64 VALU rate (~30 T op/s).
+constexpr int kPairR = OXHIP_PAIR_R;                // milestones j held in registers per thread
 constexpr int kPairJB = kPairThreads * kPairR;      // j per workgroup
-constexpr int kPairIC = 1024;                       // i per workgroup
+constexpr int kPairIC = OXHIP_PAIR_IC;              // i per workgroup
 
 constexpr int kStage = 512;                         // per-wave LDS staging of hits before they go to HBM
 
@@ -220,22 +341,35 @@ __device__ __forceinline__ void stage_flush(const PrmArgs& a, PairStage& st, uin
     st.cnt = 0;
 }
 
-// One i against the thread's kPairR milestones.  `ci` is wave-uniform: it is loaded through the scalar
+// A range of i against the thread's kPairR milestones.  `ci` is wave-uniform: it is loaded through the scalar
 // cache (s_load) and feeds the f64 VALU as a scalar operand, so the inner loop touches neither LDS nor
 // the vector memory path.  Hits are rare (a few 1e-4 of all pairs): one wave-uniform branch per i.
 template <int DIM, bool DIAG>
 __device__ __forceinline__ void pairs_one_i(const PrmArgs& a, PairStage& st, uint32_t lane, const double (&cj)[kPairR][DIM],
-                                            const uint32_t (&jr)[kPairR], const double* __restrict__ ms, uint32_t i,
-                                            double thr) {
-    double ci[DIM];
+                                            const uint32_t (&jr)[kPairR], const double (&ci)[DIM], uint32_t i, double thr) {
+    // distance(q_rand, other)^2 (rvss.rs:137-155: sequential sum over k) for the kPairR milestones, the four
+    // independent chains interleaved so that consecutive f64 instructions never depend on each other
+    double acc[kPairR];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) ci[k] = ms[(size_t)i * DIM + k];
+    for (int r = 0; r < kPairR; ++r) {
+        const double d = cj[r][0] - ci[0];
+        acc[r] = d * d;
+    }
+#pragma unroll
+    for (int k = 1; k < DIM; ++k) {
+        double d[kPairR];
+#pragma unroll
+        for (int r = 0; r < kPairR; ++r) d[r] = cj[r][k] - ci[k];
+#pragma unroll
+        for (int r = 0; r < kPairR; ++r) d[r] = d[r] * d[r];
+#pragma unroll
+        for (int r = 0; r < kPairR; ++r) acc[r] = acc[r] + d[r];
+    }
     bool h[kPairR];
     bool any = false;
 #pragma unroll
     for (int r = 0; r < kPairR; ++r) {
-        const double d2 = dist2<DIM>(cj[r], ci, DIM);   // distance(q_rand, other)^2, rvss.rs:137-155
-        h[r] = d2 <= thr;                                 // sqrt(d2) < connection_radius, exactly
+        h[r] = acc[r] <= thr;                             // sqrt(d2) < connection_radius, exactly
         if (DIAG) h[r] = h[r] && i < jr[r];
         any = any || h[r];
     }
@@ -247,6 +381,34 @@ __device__ __forceinline__ void pairs_one_i(const PrmArgs& a, PairStage& st, uin
             st.cnt += (uint32_t)__popcll(m);
         }
         if (st.cnt > (uint32_t)(kStage - 64 * kPairR)) stage_flush(a, st, lane);  // room for one more full i
+    }
+}
+
+// i in [lo, hi), two per trip with two scalar register sets: the coordinates of one i are in flight
+// (s_load) while the other's arithmetic runs, so the scalar-cache latency never shows.
+template <int DIM, bool DIAG>
+__device__ __forceinline__ void pairs_range(const PrmArgs& a, PairStage& st, uint32_t lane, const double (&cj)[kPairR][DIM],
+                                            const uint32_t (&jr)[kPairR], const double* __restrict__ ms, uint32_t lo,
+                                            uint32_t hi, double thr) {
+    if (lo >= hi) return;
+    double ca[DIM], cb[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) ca[k] = ms[(size_t)lo * DIM + k];
+    for (uint32_t i = lo; i < hi; i += 2) {
+        // Scalar loads return out of order, so the only wait is "all of them" (lgkmcnt(0)): each set is
+        // requested right before the other set's arithmetic and waited for right after it.
+        const uint32_t ib = i + 1 < hi ? i + 1 : i;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) cb[k] = ms[(size_t)ib * DIM + k];
+        __builtin_amdgcn_sched_barrier(0);
+        pairs_one_i<DIM, DIAG>(a, st, lane, cj, jr, ca, i, thr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint32_t ia = i + 2 < hi ? i + 2 : i;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) ca[k] = ms[(size_t)ia * DIM + k];
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < hi) pairs_one_i<DIM, DIAG>(a, st, lane, cj, jr, cb, i + 1, thr);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -272,8 +434,8 @@ __global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, cons
     PairStage st{stage[tid >> 6], 0u};
     // i below every j of the block: no index test; the rest of the range (the diagonal blocks) tests i < j
     const uint32_t i_mid = i_hi < jb0 ? i_hi : (i_lo > jb0 ? i_lo : jb0);
-    for (uint32_t i = i_lo; i < i_mid; ++i) pairs_one_i<DIM, false>(a, st, lane, cj, jr, ms, i, thr);
-    for (uint32_t i = i_mid; i < i_hi; ++i) pairs_one_i<DIM, true>(a, st, lane, cj, jr, ms, i, thr);
+    pairs_range<DIM, false>(a, st, lane, cj, jr, ms, i_lo, i_mid, thr);
+    pairs_range<DIM, true>(a, st, lane, cj, jr, ms, i_mid, i_hi, thr);
     stage_flush(a, st, lane);
 }
 
@@ -281,29 +443,40 @@ __global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, cons
 // 3. check_motion per candidate pair (from = the newer milestone j, to = the older one i: prm.rs:134)
 
 template <int DIM>
-__global__ __launch_bounds__(256) void prm_edge_kernel(DevParams p, PrmArgs a, uint32_t n_cand) {
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= n_cand) return;
-    const uint2 pr = a.cand[c];
-    double from[DIM], to[DIM];
+__global__ __launch_bounds__(256) void prm_edge_kernel(DevParams p, PrmArgs a, uint32_t n_cand, uint32_t key_shift) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    bool ok = false;
+    uint2 pr = make_uint2(0u, 0u);
+    if (c < n_cand) {
+        pr = a.cand[c];
+        double from[DIM], to[DIM];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) {
-        from[k] = a.ms[(size_t)pr.x * DIM + k];
-        to[k] = a.ms[(size_t)pr.y * DIM + k];
+        for (int k = 0; k < DIM; ++k) {
+            from[k] = a.ms[(size_t)pr.x * DIM + k];
+            to[k] = a.ms[(size_t)pr.y * DIM + k];
+        }
+        ok = motion_valid_seq<DIM>(p, from, to);
     }
-    if (!motion_valid_seq<DIM>(p, from, to)) return;
-    const uint32_t slot = atomicAdd(&a.state->n_keys, 2u);
-    a.keys[slot] = ((uint64_t)pr.x << 32) | pr.y;       // i in j's list
-    a.keys[slot + 1] = ((uint64_t)pr.y << 32) | pr.x;   // j in i's list (prm.rs:143-145)
+    // one atomic per wave: a counter bumped once per edge serialises at the L2
+    const uint64_t bal = __ballot(ok);
+    if (bal == 0) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.state->n_keys, 2u * (uint32_t)__popcll(bal));
+    base = uni(base);
+    if (ok) {
+        const uint32_t slot = base + 2u * (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        a.keys[slot] = ((uint64_t)pr.x << key_shift) | pr.y;       // i in j's list
+        a.keys[slot + 1] = ((uint64_t)pr.y << key_shift) | pr.x;   // j in i's list (prm.rs:143-145)
+    }
 }
 
-// CSR from the sorted directed keys: offsets by binary search, neighbours = low words
+// CSR from the sorted directed keys (u << key_shift | v): offsets by binary search, neighbours = low fields
 __global__ __launch_bounds__(256) void prm_csr_kernel(const uint64_t* sorted, uint32_t n_keys, uint32_t n_nodes,
-                                                       uint32_t* offsets, uint32_t* nbrs) {
+                                                       uint32_t key_shift, uint32_t* offsets, uint32_t* nbrs) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < n_keys) nbrs[t] = (uint32_t)sorted[t];
+    if (t < n_keys) nbrs[t] = (uint32_t)(sorted[t] & ((1ull << key_shift) - 1ull));
     if (t <= n_nodes) {
-        const uint64_t key = (uint64_t)t << 32;
+        const uint64_t key = (uint64_t)t << key_shift;
         uint32_t lo = 0, hi = n_keys;
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -358,6 +531,19 @@ void launch_prm_sample(const DevParams& p, const PrmArgs& a, hipStream_t s) {
     });
 }
 
+void launch_prm_sample_spec(const DevParams& p, const PrmArgs& a, const PrmSpec& sp, uint32_t n0, hipStream_t s) {
+    const uint32_t blocks = (sp.m + kSpecThreads - 1) / kSpecThreads;
+    dim_dispatch(p.dim, [&](auto d) {
+        constexpr int D = decltype(d)::value;
+        hipLaunchKernelGGL(prm_sample_spec_kernel<D>, dim3(blocks), dim3(kSpecThreads), 0, s, p, a, sp);
+    });
+    hipLaunchKernelGGL(prm_sample_scan_kernel, dim3(1), dim3(1024), 0, s, a, sp, p.dim);
+    dim_dispatch(p.dim, [&](auto d) {
+        constexpr int D = decltype(d)::value;
+        hipLaunchKernelGGL(prm_sample_compact_kernel<D>, dim3(blocks), dim3(kSpecThreads), 0, s, a, sp, n0);
+    });
+}
+
 void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_t j1, double thr, hipStream_t s) {
     if (j1 <= j0 || j1 < 2) return;
     const uint32_t jblocks = (j1 - j0 + kPairJB - 1) / kPairJB;
@@ -369,25 +555,32 @@ void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_
     });
 }
 
+// directed keys are (u << shift) | v with shift = bits of (capacity - 1): the sort covers 2 * shift bits
+uint32_t prm_key_shift(uint32_t cap) {
+    uint32_t shift = 1;
+    while (shift < 32 && ((cap - 1) >> shift) != 0) ++shift;
+    return shift;
+}
+
 void launch_prm_edges(const DevParams& p, const PrmArgs& a, uint32_t n_cand, hipStream_t s) {
     if (n_cand == 0) return;
+    const uint32_t shift = prm_key_shift(a.cap);
     dim_dispatch(p.dim, [&](auto d) {
         constexpr int D = decltype(d)::value;
-        hipLaunchKernelGGL(prm_edge_kernel<D>, dim3((n_cand + 255) / 256), dim3(256), 0, s, p, a, n_cand);
+        hipLaunchKernelGGL(prm_edge_kernel<D>, dim3((n_cand + 255) / 256), dim3(256), 0, s, p, a, n_cand, shift);
     });
 }
 
-hipError_t prm_sort_keys(void* tmp, size_t& tmp_bytes, uint64_t* in, uint64_t* out, uint32_t n_keys, uint32_t n_nodes,
+hipError_t prm_sort_keys(void* tmp, size_t& tmp_bytes, uint64_t* in, uint64_t* out, uint32_t n_keys, uint32_t cap,
                          hipStream_t s) {
-    uint32_t bits = 33;
-    while (bits < 64 && ((uint64_t)n_nodes >> (bits - 32)) != 0) ++bits;  // high word < n_nodes
-    return rocprim::radix_sort_keys(tmp, tmp_bytes, in, out, (size_t)n_keys, 0u, bits, s);
+    return rocprim::radix_sort_keys(tmp, tmp_bytes, in, out, (size_t)n_keys, 0u, 2u * prm_key_shift(cap), s);
 }
 
-void launch_prm_csr(const uint64_t* sorted, uint32_t n_keys, uint32_t n_nodes, uint32_t* offsets, uint32_t* nbrs,
-                    hipStream_t s) {
+void launch_prm_csr(const uint64_t* sorted, uint32_t n_keys, uint32_t n_nodes, uint32_t cap, uint32_t* offsets,
+                    uint32_t* nbrs, hipStream_t s) {
     const uint32_t work = n_keys > n_nodes + 1 ? n_keys : n_nodes + 1;
-    hipLaunchKernelGGL(prm_csr_kernel, dim3((work + 255) / 256), dim3(256), 0, s, sorted, n_keys, n_nodes, offsets, nbrs);
+    hipLaunchKernelGGL(prm_csr_kernel, dim3((work + 255) / 256), dim3(256), 0, s, sorted, n_keys, n_nodes, prm_key_shift(cap),
+                       offsets, nbrs);
 }
 
 void launch_prm_query(const DevParams& p, const PrmArgs& a, uint32_t n, const PrmQuery& q, double thr, uint8_t* flags,
