@@ -23,7 +23,8 @@ struct oxhip_prm {
     double thr_conn = -1.0;   // d2 <= thr_conn  <=>  distance < connection_radius
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
-    DevBuf<double> ms, sph_c, sph_thr, box_lo, box_hi;
+    DevBuf<double> ms, sph_c, sph_thr, sph_r, box_lo, box_hi;
+    double maxabs = 1.0;      // largest |coordinate| of bounds and sphere centres (midpoint filter margin)
     DevBuf<PrmState> state;
     DevBuf<uint2> cand;
     DevBuf<uint64_t> keys, keys_sorted;
@@ -188,6 +189,8 @@ int32_t oxhip_prm_create(const oxhip_prm_config* cfg, oxhip_prm** out) {
     }
     dp.res = res;
     dp.seed = cfg->seed;
+    for (uint32_t k = 0; k < 2 * dim; ++k) h->maxabs = std::fmax(h->maxabs, std::fabs(cfg->bounds[k]));
+    dp.filt_abs = 1e-9 * h->maxabs;
     h->thr_conn = sqrt_lt_threshold(cfg->connection_radius);
 
     hipError_t e = hipSuccess;
@@ -237,7 +240,12 @@ int32_t oxhip_prm_set_spheres(oxhip_prm* h, const double* centres, const double*
     }
     OX_TRY(upload(h->sph_c, c, h->stream));
     OX_TRY(upload(h->sph_thr, thr, h->stream));
-    h->dp.n_spheres = n; h->dp.sph_c = h->sph_c.p; h->dp.sph_thr = h->sph_thr.p;
+    OX_TRY(upload(h->sph_r, std::vector<double>(radii, radii + n), h->stream));
+    h->dp.n_spheres = n; h->dp.sph_c = h->sph_c.p; h->dp.sph_thr = h->sph_thr.p; h->dp.sph_r = h->sph_r.p;
+    h->maxabs = 1.0;
+    for (uint32_t k = 0; k < 2 * dim; ++k) h->maxabs = std::fmax(h->maxabs, std::fabs(h->cfg.bounds[k]));
+    for (double v : c) h->maxabs = std::fmax(h->maxabs, std::fabs(v));
+    h->dp.filt_abs = 1e-9 * h->maxabs;
     return OXHIP_OK;
 }
 
@@ -421,8 +429,10 @@ int32_t oxhip_prm_solve(oxhip_prm* h, double timeout_s, double* path, uint32_t c
     OX_TRY(select_device(h->cfg.device));
     OX_TRY(fetch_roadmap(h));
     const uint32_t n = h->n, dim = h->cfg.dim;
+    DevParams qdp = h->dp;   // the start may lie anywhere: widen the filter's absolute margin for this launch
+    for (uint32_t k = 0; k < dim; ++k) qdp.filt_abs = std::fmax(qdp.filt_abs, 1e-9 * std::fabs(h->query.start[k]));
     HIP_TRY(hipEventRecord(h->ev[0], h->stream));
-    launch_prm_query(h->dp, h->args, n, h->query, h->thr_conn, h->flags.p, h->start_valid.p, h->stream);
+    launch_prm_query(qdp, h->args, n, h->query, h->thr_conn, h->flags.p, h->start_valid.p, h->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(h->ev[1], h->stream));
     std::vector<uint8_t> flags(n);

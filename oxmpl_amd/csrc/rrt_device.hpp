@@ -63,6 +63,9 @@ struct DevParams {
     double t_steer;         // largest d2 with sqrt(d2) <= max_distance: steer iff d2 > t_steer (exact)
     const double* sph_filt; // [n_spheres] conservative filter: d2(centre, segment midpoint) > filt => sphere cannot be hit
     uint64_t* dbg;          // optional [16] cycle stamps of workgroup 0 (diagnostic build of the resident kernel)
+    // PRM only (prm_kernels.hip): the midpoint filter's inputs for motions of any length
+    const double* sph_r;    // [n_spheres] radii as given
+    double filt_abs;        // 1e-9 * largest coordinate magnitude in play (absolute rounding margin)
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -234,3 +234,26 @@ def test_prm_radius_edge_cases_and_errors():
         with pytest.raises(capi.OxhipError) as ei:
             capi.PRMRoadmap(2, bounds, 0.5, 100)
         assert ei.value.status == status
+
+
+@pytest.mark.parametrize("dim,n_spheres,rmax", [(2, 150, 0.45), (3, 70, 1.2), (3, 64, 0.9)])
+def test_prm_many_spheres_filter_is_conservative(dim, n_spheres, rmax):
+    """more spheres than one 64-bit filter word, radii comparable to the connection radius: the midpoint filter
+    of the edge check must never drop a sphere a motion actually touches (edge lists identical to the oracle)"""
+    rng = np.random.default_rng(99 + dim)
+    centres = rng.uniform(0.0, 10.0, size=(n_spheres, dim))
+    radii = rng.uniform(0.05, rmax, size=n_spheres)
+    radii[:3] = [-1.0, 0.0, 1e-300]   # never / only exactly at the centre / denormal-ish radius
+    P = dict(dim=dim, bounds=[(0.0, 10.0)] * dim, radius=1.1 if dim == 2 else 1.6, fraction=0.05, seed=77, stream=dim,
+             max_milestones=3000, max_samples=10 ** 9, boxes=[([0.0] * dim, [0.4] * dim)],
+             spheres=[(list(map(float, c)), float(r)) for c, r in zip(centres, radii)])
+    g, o = make_gpu_prm(P), make_oracle_prm(P)
+    s, gc = [0.45] * dim, [9.5] * dim
+    g.setup(s, gc, 1.0)
+    o.setup(s, gc, 1.0)
+    g.construct_roadmap()
+    o.construct_roadmap(3000)
+    _, goff, gn = assert_same_roadmap(g, o)
+    t = g.last_timing()
+    assert 2 * t["candidates"] > len(gn) > 0      # some in-radius pairs were rejected by check_motion
+    assert_same_query(g, o)
