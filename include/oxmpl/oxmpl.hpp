@@ -50,11 +50,11 @@ namespace base {
 enum class PlanningError { Timeout, NoSolutionFound, PlannerUninitialised, InvalidStartState, UnsampledStateSpace };
 inline const char* to_string(PlanningError e) {
     switch (e) {
-        case PlanningError::Timeout: return "Planner timed out.";
+        case PlanningError::Timeout: return "No solution found within timeout.";
         case PlanningError::NoSolutionFound: return "No solution found.";
-        case PlanningError::PlannerUninitialised: return "Planner was not set up before calling solve.";
-        case PlanningError::InvalidStartState: return "Start state is invalid.";
-        default: return "State space has not been sampled.";
+        case PlanningError::PlannerUninitialised: return "<Planner>.setup() was not called, thus Planner is uninitialised.";
+        case PlanningError::InvalidStartState: return "Start state is not valid in the current StateSpace.";
+        default: return "StateSpace is not sampled. Either Tree or Roadmap is empty.";
     }
 }
 struct StateSpaceError {
@@ -258,6 +258,132 @@ class RRTConnect : public RRT {
 
   protected:
     uint32_t planner_kind() const override { return OXHIP_PLANNER_RRT_CONNECT; }
+};
+
+// PRM (prm.rs:48-57): roadmap built and queried on the GPU.
+class PRM {
+  public:
+    double timeout;             // seconds of roadmap construction (prm.rs:50); the device path also stops at max_milestones
+    double connection_radius;   // prm.rs:52
+    // build-defined termination and RNG key
+    uint32_t max_milestones = 16384;
+    uint64_t max_samples = 0;   // 0 = unlimited
+    uint64_t seed = 0;
+    uint64_t stream = 0;
+    int device = 0;
+
+    PRM(double timeout_, double connection_radius_) : timeout(timeout_), connection_radius(connection_radius_) {}  // prm.rs:70-78
+    ~PRM() { reset(); }
+    PRM(const PRM&) = delete;
+    PRM& operator=(const PRM&) = delete;
+
+    // Planner::setup (prm.rs:217-225)
+    void setup(std::shared_ptr<base::ProblemDefinition> problem_def, std::shared_ptr<base::StateValidityChecker> validity_checker) {
+        reset();
+        pd_ = std::move(problem_def);
+        last_status_ = OXHIP_OK;
+        if (!pd_ || !validity_checker || !pd_->space || !pd_->goal || pd_->start_states.empty()) { last_status_ = OXHIP_ERR_BAD_ARG; return; }
+        const auto& sp = *pd_->space;
+        oxhip_prm_config cfg{};
+        cfg.struct_size = sizeof cfg;
+        cfg.dim = (uint32_t)sp.dimension;
+        for (std::size_t k = 0; k < sp.bounds.size() && k < OXHIP_MAX_DIM; ++k) {
+            cfg.bounds[2 * k] = sp.bounds[k].first;
+            cfg.bounds[2 * k + 1] = sp.bounds[k].second;
+        }
+        cfg.timeout = timeout;
+        cfg.connection_radius = connection_radius;
+        cfg.lvs_fraction = sp.longest_valid_segment_fraction;
+        cfg.max_milestones = max_milestones;
+        cfg.max_samples = max_samples;
+        cfg.seed = seed;
+        cfg.stream = stream;
+        cfg.device = device;
+        if ((last_status_ = oxhip_prm_create(&cfg, &prm_)) != OXHIP_OK) return;
+        std::vector<double> c, r, lo, hi;
+        for (auto& s : validity_checker->spheres()) { c.insert(c.end(), s.centre.begin(), s.centre.end()); r.push_back(s.radius); }
+        for (auto& b : validity_checker->boxes()) { lo.insert(lo.end(), b.lo.begin(), b.lo.end()); hi.insert(hi.end(), b.hi.begin(), b.hi.end()); }
+        if (!r.empty() && (last_status_ = oxhip_prm_set_spheres(prm_, c.data(), r.data(), (uint32_t)r.size())) != OXHIP_OK) return;
+        if (!lo.empty() && (last_status_ = oxhip_prm_set_boxes(prm_, lo.data(), hi.data(), (uint32_t)(lo.size() / sp.dimension))) != OXHIP_OK) return;
+        const auto target = pd_->goal->target();
+        last_status_ = oxhip_prm_setup(prm_, pd_->start_states[0].values.data(), target.values.data(), pd_->goal->radius());
+    }
+
+    // PRM::set_problem_definition (prm.rs:88-90): keeps the roadmap
+    void set_problem_definition(std::shared_ptr<base::ProblemDefinition> pd) {
+        pd_ = std::move(pd);
+        if (prm_ && pd_ && pd_->goal && !pd_->start_states.empty()) {
+            const auto target = pd_->goal->target();
+            last_status_ = oxhip_prm_set_problem(prm_, pd_->start_states[0].values.data(), target.values.data(), pd_->goal->radius());
+        }
+    }
+
+    // PRM::construct_roadmap (prm.rs:96-154)
+    Result<bool, base::PlanningError> construct_roadmap() {
+        if (!prm_ || last_status_ != OXHIP_OK) return base::PlanningError::PlannerUninitialised;  // prm.rs:97-104
+        last_status_ = oxhip_prm_construct_roadmap(prm_);
+        if (last_status_ != OXHIP_OK) return base::PlanningError::PlannerUninitialised;
+        return true;
+    }
+
+    // Planner::solve (prm.rs:227-307)
+    Result<base::Path, base::PlanningError> solve(std::chrono::duration<double> timeout_) {
+        if (!prm_) return base::PlanningError::PlannerUninitialised;
+        uint32_t len = 0;
+        int32_t st = oxhip_prm_solve(prm_, timeout_.count(), nullptr, 0, &len);
+        if (st != OXHIP_OK) return to_error(st);
+        const std::size_t dim = pd_->space->dimension;
+        std::vector<double> flat((std::size_t)len * dim);
+        if ((st = oxhip_prm_solve(prm_, timeout_.count(), flat.data(), len, &len)) != OXHIP_OK) return to_error(st);
+        base::Path path;
+        for (uint32_t i = 0; i < len; ++i)
+            path.states.emplace_back(std::vector<double>(flat.begin() + i * dim, flat.begin() + (i + 1) * dim));
+        return path;
+    }
+
+    // PRM::get_roadmap (prm.rs:82-84): milestone count and, per node, its `edges`
+    uint32_t num_milestones() const {
+        uint32_t n = 0;
+        if (prm_) (void)oxhip_prm_get_sizes(prm_, &n, nullptr, nullptr);
+        return n;
+    }
+    struct Roadmap { std::vector<base::RealVectorState> states; std::vector<std::vector<uint32_t>> edges; };
+    Roadmap get_roadmap() const {
+        Roadmap rm;
+        if (!prm_) return rm;
+        uint32_t n = 0;
+        uint64_t e = 0;
+        (void)oxhip_prm_get_sizes(prm_, &n, &e, nullptr);
+        const std::size_t dim = pd_->space->dimension;
+        std::vector<double> flat((std::size_t)n * dim);
+        std::vector<uint64_t> off((std::size_t)n + 1);
+        std::vector<uint32_t> nb((std::size_t)e);
+        if (oxhip_prm_get_roadmap(prm_, flat.data(), n, off.data(), nb.data(), e) != OXHIP_OK) return rm;
+        for (uint32_t i = 0; i < n; ++i) {
+            rm.states.emplace_back(std::vector<double>(flat.begin() + i * dim, flat.begin() + (i + 1) * dim));
+            rm.edges.emplace_back(nb.begin() + off[i], nb.begin() + off[i + 1]);
+        }
+        return rm;
+    }
+    int32_t last_status() const { return last_status_; }
+
+  private:
+    static base::PlanningError to_error(int32_t st) {
+        switch (st) {
+            case OXHIP_ERR_TIMEOUT: return base::PlanningError::Timeout;
+            case OXHIP_ERR_PLANNER_UNINITIALISED: return base::PlanningError::PlannerUninitialised;
+            case OXHIP_ERR_INVALID_START_STATE: return base::PlanningError::InvalidStartState;
+            case OXHIP_ERR_UNSAMPLED_STATE_SPACE: return base::PlanningError::UnsampledStateSpace;
+            default: return base::PlanningError::NoSolutionFound;
+        }
+    }
+    void reset() {
+        if (prm_) (void)oxhip_prm_destroy(prm_);
+        prm_ = nullptr;
+    }
+    oxhip_prm* prm_ = nullptr;
+    std::shared_ptr<base::ProblemDefinition> pd_;
+    int32_t last_status_ = OXHIP_ERR_PLANNER_UNINITIALISED;
 };
 
 }  // namespace geometric

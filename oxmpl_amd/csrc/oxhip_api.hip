@@ -50,11 +50,11 @@ int32_t oxhip_abi_version(void) { return OXHIP_ABI_VERSION; }
 const char* oxhip_status_string(int32_t s) {
     switch (s) {
         case OXHIP_OK: return "ok";
-        case OXHIP_ERR_TIMEOUT: return "Planner timed out.";  // wording of error.rs Display
+        case OXHIP_ERR_TIMEOUT: return "No solution found within timeout.";  // Display strings of error.rs:110-136
         case OXHIP_ERR_NO_SOLUTION_FOUND: return "No solution found.";
-        case OXHIP_ERR_PLANNER_UNINITIALISED: return "Planner was not set up before calling solve.";
-        case OXHIP_ERR_INVALID_START_STATE: return "Start state is invalid.";
-        case OXHIP_ERR_UNSAMPLED_STATE_SPACE: return "State space has not been sampled.";
+        case OXHIP_ERR_PLANNER_UNINITIALISED: return "<Planner>.setup() was not called, thus Planner is uninitialised.";
+        case OXHIP_ERR_INVALID_START_STATE: return "Start state is not valid in the current StateSpace.";
+        case OXHIP_ERR_UNSAMPLED_STATE_SPACE: return "StateSpace is not sampled. Either Tree or Roadmap is empty.";
         case OXHIP_ERR_BAD_ARG: return "bad argument";
         case OXHIP_ERR_UNBOUNDED: return "Cannot sample uniformly because a dimension is unbounded.";
         case OXHIP_ERR_ZERO_VOLUME: return "Cannot sample from a region with zero volume.";

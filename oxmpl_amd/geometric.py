@@ -13,9 +13,11 @@ from . import capi
 from .base import Path, ProblemDefinition, RealVectorState, SphereBoxValidityChecker
 
 _MESSAGES = {  # Display strings of PlanningError (oxmpl/src/base/error.rs:110-136)
-    capi.ERR_TIMEOUT: "Planner timed out.",
+    capi.ERR_TIMEOUT: "No solution found within timeout.",
     capi.ERR_NO_SOLUTION_FOUND: "No solution found.",
-    capi.ERR_PLANNER_UNINITIALISED: "Planner was not set up before calling solve.",
+    capi.ERR_PLANNER_UNINITIALISED: "<Planner>.setup() was not called, thus Planner is uninitialised.",
+    capi.ERR_INVALID_START_STATE: "Start state is not valid in the current StateSpace.",
+    capi.ERR_UNSAMPLED_STATE_SPACE: "StateSpace is not sampled. Either Tree or Roadmap is empty.",
 }
 
 
@@ -83,3 +85,79 @@ class RRTConnect(RRT):
     @property
     def num_nodes(self):
         return int(self._batch.counts()["nodes"][0]) + int(self._batch.goal_counts()["nodes"][0])
+
+
+class PRM:
+    """oxmpl_py.geometric.PRM (oxmpl-py/src/geometric/prm.rs:30-206; planner: oxmpl/src/geometric/planners/prm.rs).
+
+        planner = PRM(timeout=5.0, connection_radius=0.5, problem_definition=problem_def)
+        planner.setup(SphereBoxValidityChecker(...))
+        planner.construct_roadmap()
+        path = planner.solve(timeout_secs=5.0)
+
+    The reference samples for `timeout` seconds of wall clock; the device path also stops at `max_milestones`
+    (a GPU fills five seconds with tens of millions of milestones).  `seed` / `stream` key the sampler."""
+
+    def __init__(self, timeout, connection_radius, problem_definition, max_milestones=16384, max_samples=0, seed=0,
+                 stream=0, device=0):
+        if not isinstance(problem_definition, ProblemDefinition):
+            raise TypeError("problem_definition must be a ProblemDefinition")
+        self.timeout, self.connection_radius = float(timeout), float(connection_radius)
+        self._pd = problem_definition
+        self._opts = dict(max_milestones=max_milestones, max_samples=max_samples, seed=seed, stream=stream, device=device)
+        self._prm = None
+
+    def setup(self, validity_checker):
+        """Planner::setup (prm.rs:217-225): stores problem and checker, clears the roadmap"""
+        if not isinstance(validity_checker, SphereBoxValidityChecker):
+            raise TypeError("the GPU path cannot call a Python function per interpolated state; "
+                            "describe the obstacles with oxmpl_amd.base.SphereBoxValidityChecker")
+        pd = self._pd
+        if self._prm is not None:
+            self._prm.close()
+        try:
+            g = capi.PRMRoadmap(pd.space.dimension, pd.space.bounds, self.connection_radius, timeout=self.timeout,
+                                lvs_fraction=pd.space.longest_valid_segment_fraction, **self._opts)
+        except capi.OxhipError as e:
+            if e.status in (capi.ERR_UNBOUNDED, capi.ERR_ZERO_VOLUME, capi.ERR_BAD_ARG):
+                raise ValueError(str(e)) from None
+            raise
+        if validity_checker.spheres:
+            g.set_spheres([c for c, _ in validity_checker.spheres], [r for _, r in validity_checker.spheres])
+        if validity_checker.boxes:
+            g.set_boxes([lo for lo, _ in validity_checker.boxes], [hi for _, hi in validity_checker.boxes])
+        g.setup(pd.start_state.values, pd.goal.target.values, float(pd.goal.radius))
+        self._prm = g
+
+    def set_problem_definition(self, problem_definition):
+        """PRM::set_problem_definition (prm.rs:88-90): new start / goal on the roadmap already built"""
+        if not isinstance(problem_definition, ProblemDefinition):
+            raise TypeError("problem_definition must be a ProblemDefinition")
+        self._pd = problem_definition
+        if self._prm is not None:
+            self._prm.set_problem(problem_definition.start_state.values, problem_definition.goal.target.values,
+                                  float(problem_definition.goal.radius))
+
+    def construct_roadmap(self):
+        if self._prm is None:
+            raise Exception(_MESSAGES[capi.ERR_PLANNER_UNINITIALISED])
+        self._prm.construct_roadmap()
+
+    def solve(self, timeout_secs):
+        """Planner::solve (prm.rs:227-307); errors surface as Exception(message) like the reference
+        (oxmpl-py/src/geometric/prm.rs:120-145)"""
+        if self._prm is None:
+            raise Exception(_MESSAGES[capi.ERR_PLANNER_UNINITIALISED])
+        st, path = self._prm.solve(float(timeout_secs))
+        if st != capi.OK:
+            raise Exception(_MESSAGES.get(int(st), capi.status_string(int(st))))
+        return Path([RealVectorState(row) for row in path])
+
+    def get_roadmap(self):
+        """PRM::get_roadmap (prm.rs:82-84) as (states, offsets, neighbours): node i's edges are
+        neighbours[offsets[i]:offsets[i+1]]"""
+        return self._prm.roadmap()
+
+    @property
+    def num_milestones(self):
+        return 0 if self._prm is None else self._prm.sizes()[0]

@@ -11,12 +11,12 @@ from oxmpl_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path):
+def _build(tmp_path, name="test_rrt_rvss"):
     capi.build_library()
-    exe = str(tmp_path / "test_rrt_rvss")
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "oxmpl_amd", "lib")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "test_rrt_rvss.cpp"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            "-L", libdir, "-loxmpl_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
@@ -35,3 +35,19 @@ def test_cpp_twin_of_reference_rrt_test(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "RRT planner test passed!" in r.stdout
+
+
+def test_cpp_prm_mirror_builds_and_refuses_without_gpu(tmp_path):
+    exe = _build(tmp_path, "test_prm_rvss")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode in (0, 77), r.stdout + r.stderr
+    if r.returncode == 77:
+        assert "refused as designed" in r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_twin_of_reference_prm_test(tmp_path):
+    exe = _build(tmp_path, "test_prm_rvss")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PRM planner test passed!" in r.stdout
