@@ -57,7 +57,8 @@ typedef enum oxhip_stop_reason {
 
 typedef enum oxhip_planner_kind {
     OXHIP_PLANNER_RRT = 0,         /* geometric::RRT         oxmpl/src/geometric/planners/rrt.rs */
-    OXHIP_PLANNER_RRT_CONNECT = 1  /* geometric::RRTConnect  oxmpl/src/geometric/planners/rrt_connect.rs (stream kernel only) */
+    OXHIP_PLANNER_RRT_CONNECT = 1, /* geometric::RRTConnect  oxmpl/src/geometric/planners/rrt_connect.rs (stream kernel only) */
+    OXHIP_PLANNER_RRT_STAR = 2     /* geometric::RRTStar     oxmpl/src/geometric/planners/rrt_star.rs (stream kernel only) */
 } oxhip_planner_kind;
 
 typedef enum oxhip_kernel_kind {
@@ -84,7 +85,9 @@ typedef struct oxhip_rrt_config {
     uint64_t seed;                      /* RNG key: ChaCha12 key = LE(seed)||0^24, stream id = first_problem_id + p */
     uint64_t first_problem_id;          /* global id of problem 0 of this batch (problem-parallel sharding) */
     int32_t  device;                    /* HIP device ordinal */
-    uint32_t planner;                   /* oxhip_planner_kind: 0 = RRT (rrt.rs), 1 = RRTConnect (rrt_connect.rs) */
+    uint32_t planner;                   /* oxhip_planner_kind: 0 = RRT (rrt.rs), 1 = RRTConnect (rrt_connect.rs), 2 = RRT* */
+    double   search_radius;             /* RRTStar::search_radius (rrt_star.rs:45): neighbours are the nodes with
+                                           distance < search_radius (strict); ignored by the other planners */
 } oxhip_rrt_config;
 
 typedef struct oxhip_rrt_batch oxhip_rrt_batch;
@@ -155,6 +158,10 @@ int32_t oxhip_rrt_batch_get_path(oxhip_rrt_batch* b, uint32_t problem, double* s
 int32_t oxhip_rrt_batch_get_goal_counts(oxhip_rrt_batch* b, uint32_t* nodes /*[P]*/, int32_t* end_node /*[P]*/);
 int32_t oxhip_rrt_batch_get_goal_tree(oxhip_rrt_batch* b, uint32_t problem, double* states, int32_t* parents,
                                       uint32_t cap_nodes, uint32_t* n_nodes);
+
+/* RRT* only: Node::cost (rrt_star.rs:26) of every node of problem `problem`, in node order */
+int32_t oxhip_rrt_batch_get_costs(oxhip_rrt_batch* b, uint32_t problem, double* costs, uint32_t cap_nodes,
+                                  uint32_t* n_nodes);
 
 /* HIP-event time (ms) of the kernels of the last solve call, their launch count, and which
  * kernel ran (oxhip_kernel_kind). */

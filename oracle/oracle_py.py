@@ -103,6 +103,18 @@ def lib():
         L.orc_rrtc_get_path.restype = C.c_uint32
         L.orc_rrt_solve_many.argtypes = [C.POINTER(C.c_void_p), C.c_uint32, C.c_uint64, C.c_int,
                                          C.c_uint32]
+        L.orc_rrts_new.argtypes = [C.c_uint32, _dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_int,
+                                   C.c_uint64, C.c_uint64, C.POINTER(C.c_int)]
+        L.orc_rrts_new.restype = C.c_void_p
+        L.orc_rrts_free.argtypes = [C.c_void_p]
+        L.orc_rrts_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.orc_rrts_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.orc_rrts_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.orc_rrts_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
+        L.orc_rrts_base.argtypes = [C.c_void_p]
+        L.orc_rrts_base.restype = C.c_void_p
+        L.orc_rrts_get_costs.argtypes = [C.c_void_p, _dp]
+        L.orc_rrts_get_costs.restype = None
         _u32p = C.POINTER(C.c_uint32)
         L.orc_prm_new.argtypes = [C.c_uint32, _dp, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
                                   C.POINTER(C.c_int)]
@@ -423,3 +435,51 @@ class OraclePRM:
         out = np.zeros(max(n, 1), dtype=np.uint32)
         lib().orc_prm_get_goal_indices(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)), n)
         return out[:n]
+
+
+class OracleRRTStar(OracleRRT):
+    """oxmpl RRTStar<RealVectorState, RealVectorStateSpace, BallGoal> (rrt_star.rs).  The tree, counters and path
+    getters are OracleRRT's, reading the wrapped planner; `costs()` adds Node::cost."""
+
+    def __init__(self, dim, bounds, max_distance, goal_bias, search_radius, lvs_fraction=0.05, max_nodes=10000,
+                 stop_at_goal=True, seed=0, problem_id=0):
+        self.dim = dim
+        b, pb = _d(np.asarray(bounds, dtype=np.float64).reshape(-1))
+        st = C.c_int()
+        self.hs = lib().orc_rrts_new(dim, pb, max_distance, goal_bias, search_radius, lvs_fraction, max_nodes,
+                                     int(bool(stop_at_goal)), seed, problem_id, C.byref(st))
+        if not self.hs:
+            raise ValueError("orc_rrts_new failed with status %d" % st.value)
+        self.h = lib().orc_rrts_base(self.hs)   # borrowed: freed with hs
+
+    def __del__(self):
+        if getattr(self, "hs", None):
+            lib().orc_rrts_free(self.hs)
+            self.hs = None
+            self.h = None
+
+    def set_spheres(self, centres, radii):
+        c, pc = _d(np.asarray(centres, dtype=np.float64).reshape(-1, self.dim))
+        r, pr = _d(radii)
+        lib().orc_rrts_set_spheres(self.hs, pc, pr, r.size)
+
+    def set_boxes(self, lo, hi):
+        l, pl = _d(np.asarray(lo, dtype=np.float64).reshape(-1, self.dim))
+        h, ph = _d(np.asarray(hi, dtype=np.float64).reshape(-1, self.dim))
+        lib().orc_rrts_set_boxes(self.hs, pl, ph, l.shape[0])
+
+    def setup(self, start, goal_centre, goal_radius):
+        s, ps = _d(start)
+        g, pg = _d(goal_centre)
+        return lib().orc_rrts_setup(self.hs, ps, pg, goal_radius)
+
+    def set_tree(self, states, parents):
+        raise NotImplementedError("RRT* trees carry costs; warm starts are not defined")
+
+    def solve(self, max_iterations, timeout_s=float("inf")):
+        return lib().orc_rrts_solve(self.hs, max_iterations, timeout_s)
+
+    def costs(self):
+        out = np.empty(self.num_nodes, dtype=np.float64)
+        lib().orc_rrts_get_costs(self.hs, out.ctypes.data_as(_dp))
+        return out

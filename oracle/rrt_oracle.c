@@ -488,6 +488,159 @@ uint32_t orc_nearest(const double* nodes, uint32_t n, uint32_t dim, const double
 }
 
 /* ------------------------------------------------------------------------- */
+/* RRT*: rrt_star.rs:39-289                                                   */
+/* ------------------------------------------------------------------------- */
+
+struct orc_rrts {
+    orc_rrt* a;            /* tree (state + parent_index), space, checker, rng, goal, counters */
+    double* cost;          /* Node::cost (rrt_star.rs:26), parallel to a->tree */
+    uint32_t cap_cost;
+    double search_radius;  /* rrt_star.rs:45 */
+};
+
+orc_rrts* orc_rrts_new(uint32_t dim, const double* bounds, double max_distance, double goal_bias, double search_radius,
+                       double lvs_fraction, uint32_t max_nodes, int stop_at_goal, uint64_t seed, uint64_t problem_id,
+                       int* status) {
+    orc_rrt* a = orc_rrt_new(dim, bounds, max_distance, goal_bias, lvs_fraction, max_nodes, stop_at_goal, seed, problem_id, status);
+    if (!a) return NULL;
+    orc_rrts* r = (orc_rrts*)calloc(1, sizeof *r);
+    r->a = a;
+    r->search_radius = search_radius;
+    return r;
+}
+
+void orc_rrts_free(orc_rrts* r) {
+    if (!r) return;
+    free(r->cost);
+    orc_rrt_free(r->a);
+    free(r);
+}
+
+int orc_rrts_set_spheres(orc_rrts* r, const double* c, const double* rad, uint32_t n) { return orc_rrt_set_spheres(r->a, c, rad, n); }
+int orc_rrts_set_boxes(orc_rrts* r, const double* lo, const double* hi, uint32_t n) { return orc_rrt_set_boxes(r->a, lo, hi, n); }
+
+static void rrts_push_cost(orc_rrts* r, double c) {
+    if (r->a->n > r->cap_cost) {
+        r->cap_cost = r->cap_cost ? r->cap_cost * 2 : 4;
+        while (r->cap_cost < r->a->n) r->cap_cost *= 2;
+        r->cost = (double*)realloc(r->cost, sizeof(double) * r->cap_cost);
+    }
+    r->cost[r->a->n - 1] = c;
+}
+
+/* rrt_star.rs:148-168: tree = [Node{start, None, 0.0}] */
+int orc_rrts_setup(orc_rrts* r, const double* start, const double* goal_centre, double goal_radius) {
+    orc_rrt_setup(r->a, start, goal_centre, goal_radius);
+    rrts_push_cost(r, 0.0);
+    return ORC_SOLVED;
+}
+
+/* rrt_star.rs:170-289 with the build's iteration budget / node cap next to the wall clock */
+int orc_rrts_solve(orc_rrts* r, uint64_t max_iterations, double timeout_s) {
+    orc_rrt* a = r->a;
+    if (!a->is_setup) return ORC_PLANNER_UNINITIALISED;
+    if (a->stop_at_goal && a->goal_node >= 0) return ORC_SOLVED;
+    const uint32_t dim = a->dim;
+    double start_time = now_s();
+    a->stop_reason = ORC_STOP_ITERATIONS;
+    uint32_t* neighbours = NULL;
+    uint32_t cap_nb = 0;
+    for (uint64_t it = 0; it < max_iterations; ++it) {
+        if (now_s() - start_time > timeout_s) { a->stop_reason = ORC_STOP_TIMEOUT; free(neighbours); return ORC_TIMEOUT; } /* :175-177 */
+        if (a->n >= a->max_nodes) { a->stop_reason = ORC_STOP_NODES; break; }
+        /* 2. sample (:180-187) */
+        double* q_rand = (double*)malloc(sizeof(double) * dim);
+        if (orc_random_bool(&a->rng, a->goal_bias)) {
+            memcpy(q_rand, a->goal_centre, sizeof(double) * dim);
+        } else {
+            for (uint32_t k = 0; k < dim; ++k) q_rand[k] = orc_random_range(&a->rng, a->bounds[2 * k], a->bounds[2 * k + 1]);
+        }
+        /* 3. nearest (:190-200) */
+        uint32_t nearest = 0;
+        double min_dist = orc_distance(a->tree[0].values, q_rand, dim);
+        for (uint32_t i = 1; i < a->n; ++i) {
+            double d = orc_distance(a->tree[i].values, q_rand, dim);
+            if (d < min_dist) { min_dist = d; nearest = i; }
+        }
+        const double* q_near = a->tree[nearest].values;
+        /* 4. steer (:203-209) */
+        double* q_new = dup_vec(q_near, dim);
+        if (min_dist > a->max_distance) {
+            double t = a->max_distance / min_dist;
+            orc_interpolate(q_near, q_rand, t, q_new, dim);
+        } else {
+            memcpy(q_new, q_rand, sizeof(double) * dim);
+        }
+        /* 5. check_motion(q_near, q_new) (:212-214) */
+        int ok = check_motion(a, q_near, q_new);
+        uint64_t h = fnv_mix(a->checksum, (uint64_t)nearest);
+        for (uint32_t k = 0; k < dim; ++k) {
+            uint64_t b;
+            memcpy(&b, &q_new[k], sizeof b);
+            h = fnv_mix(h, b);
+        }
+        h = fnv_mix(h, (uint64_t)ok);
+        a->iterations++;
+        if (!ok) { a->checksum = h; free(q_new); free(q_rand); continue; }
+        a->accepted++;
+        /* find_neighbours (:121-131): distance(node.state, tree[i].state) < search_radius, ascending i */
+        uint32_t n_nb = 0;
+        for (uint32_t i = 0; i < a->n; ++i)
+            if (orc_distance(q_new, a->tree[i].values, dim) < r->search_radius) {
+                if (n_nb == cap_nb) { cap_nb = cap_nb ? cap_nb * 2 : 16; neighbours = (uint32_t*)realloc(neighbours, sizeof(uint32_t) * cap_nb); }
+                neighbours[n_nb++] = i;
+            }
+        /* 6. choose parent (:225-241); cost(current, neighbour) = neighbour.cost + distance(current, neighbour) (:104-113) */
+        uint32_t best_parent = nearest;
+        double min_cost = r->cost[nearest] + orc_distance(q_new, a->tree[nearest].values, dim);
+        for (uint32_t e = 0; e < n_nb; ++e) {
+            uint32_t nb = neighbours[e];
+            double c = r->cost[nb] + orc_distance(q_new, a->tree[nb].values, dim);
+            if (c < min_cost && check_motion(a, a->tree[nb].values, q_new)) { min_cost = c; best_parent = nb; }
+        }
+        /* 7. push (:244-250) */
+        push_node(a, q_new, (int64_t)best_parent);
+        rrts_push_cost(r, min_cost);
+        const uint32_t new_idx = a->n - 1;
+        /* 8. rewire (:253-282) */
+        uint64_t rew_cnt = 0, rew_sum = 0;
+        for (uint32_t e = 0; e < n_nb; ++e) {
+            uint32_t nb = neighbours[e];
+            if (a->tree[new_idx].parent == (int64_t)nb) continue;                                  /* :258-260 */
+            double c2 = r->cost[new_idx] + orc_distance(a->tree[nb].values, a->tree[new_idx].values, dim);  /* cost(neighbour, new) */
+            if (c2 < r->cost[nb] && check_motion(a, a->tree[new_idx].values, a->tree[nb].values)) {
+                a->tree[nb].parent = (int64_t)new_idx;
+                r->cost[nb] = c2;
+                rew_cnt++;
+                rew_sum += nb;
+            }
+        }
+        h = fnv_mix(h, (uint64_t)best_parent);
+        {
+            uint64_t b;
+            memcpy(&b, &min_cost, sizeof b);
+            h = fnv_mix(h, b);
+        }
+        h = fnv_mix(h, rew_cnt);
+        a->checksum = fnv_mix(h, rew_sum);
+        /* 9. goal (:285-288) */
+        int hit = 0;
+        if (goal_is_satisfied(a, q_new)) {
+            if (a->goal_node < 0) a->goal_node = (int32_t)new_idx;
+            hit = 1;
+        }
+        free(q_new);
+        free(q_rand);
+        if (hit && a->stop_at_goal) { a->stop_reason = ORC_STOP_GOAL; free(neighbours); return ORC_SOLVED; }
+    }
+    free(neighbours);
+    return (a->goal_node >= 0) ? ORC_SOLVED : ORC_NO_SOLUTION_FOUND;
+}
+
+orc_rrt* orc_rrts_base(orc_rrts* r) { return r->a; }
+void orc_rrts_get_costs(const orc_rrts* r, double* out) { memcpy(out, r->cost, sizeof(double) * r->a->n); }
+
+/* ------------------------------------------------------------------------- */
 /* RRTConnect: rrt_connect.rs:86-309                                          */
 /* ------------------------------------------------------------------------- */
 

@@ -120,6 +120,22 @@ int32_t orc_rrtc_stop_reason(const orc_rrtc* r);
 void orc_rrtc_get_tree(const orc_rrtc* r, int which, double* states, int32_t* parents);
 uint32_t orc_rrtc_get_path(const orc_rrtc* r, double* out, uint32_t cap);
 
+/* ---- RRT* (oxmpl/src/geometric/planners/rrt_star.rs:39-289) ----
+ * Wraps an orc_rrt (tree, space, checker, RNG, goal, counters: use orc_rrts_base() with the orc_rrt_* getters)
+ * and adds Node::cost.  The per-iteration checksum also folds in the chosen parent, the new node's cost and
+ * the count / index sum of the rewired neighbours. */
+typedef struct orc_rrts orc_rrts;
+orc_rrts* orc_rrts_new(uint32_t dim, const double* bounds, double max_distance, double goal_bias, double search_radius,
+                       double lvs_fraction, uint32_t max_nodes, int stop_at_goal, uint64_t seed, uint64_t problem_id,
+                       int* status);
+void orc_rrts_free(orc_rrts* r);
+int orc_rrts_set_spheres(orc_rrts* r, const double* centres, const double* radii, uint32_t n);
+int orc_rrts_set_boxes(orc_rrts* r, const double* lo, const double* hi, uint32_t n);
+int orc_rrts_setup(orc_rrts* r, const double* start, const double* goal_centre, double goal_radius);
+int orc_rrts_solve(orc_rrts* r, uint64_t max_iterations, double timeout_s);
+orc_rrt* orc_rrts_base(orc_rrts* r);
+void orc_rrts_get_costs(const orc_rrts* r, double* out /*[n]*/);
+
 /* run many independent problems on `threads` host threads (cpu_baseline leg) */
 int orc_rrt_solve_many(orc_rrt** planners, uint32_t n, uint64_t max_iterations, int freeze,
                        uint32_t threads);

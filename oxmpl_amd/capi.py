@@ -19,7 +19,7 @@ ERR_INVALID_START_STATE, ERR_UNSAMPLED_STATE_SPACE = 4, 5
 ERR_BAD_ARG, ERR_UNBOUNDED, ERR_ZERO_VOLUME, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE = 16, 17, 18, 19, 32, 33
 STOP_NONE, STOP_GOAL, STOP_ITERATIONS, STOP_NODES, STOP_TIMEOUT = -1, 0, 1, 2, 3
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT, KERNEL_PRUNED = 0, 1, 2, 3
-PLANNER_RRT, PLANNER_RRT_CONNECT = 0, 1
+PLANNER_RRT, PLANNER_RRT_CONNECT, PLANNER_RRT_STAR = 0, 1, 2
 
 # every symbol include/oxmpl_hip.h declares (tests check the library exports them all)
 EXPORTS = [
@@ -27,7 +27,7 @@ EXPORTS = [
     "oxhip_rrt_batch_create", "oxhip_rrt_batch_destroy", "oxhip_rrt_batch_set_spheres",
     "oxhip_rrt_batch_set_boxes", "oxhip_rrt_batch_setup", "oxhip_rrt_batch_set_tree", "oxhip_rrt_batch_solve",
     "oxhip_rrt_batch_get_counts", "oxhip_rrt_batch_get_tree", "oxhip_rrt_batch_get_path",
-    "oxhip_rrt_batch_get_goal_counts", "oxhip_rrt_batch_get_goal_tree",
+    "oxhip_rrt_batch_get_goal_counts", "oxhip_rrt_batch_get_goal_tree", "oxhip_rrt_batch_get_costs",
     "oxhip_rrt_batch_last_timing", "oxhip_rrt_batch_enable_stamps", "oxhip_rrt_batch_get_stamps",
     "oxhip_nn_argmin_batch", "oxhip_distance_batch",
     "oxhip_interpolate_batch", "oxhip_rrt_batch_is_valid", "oxhip_rrt_batch_check_motion",
@@ -44,7 +44,7 @@ class Config(C.Structure):
         ("max_distance", C.c_double), ("goal_bias", C.c_double), ("lvs_fraction", C.c_double),
         ("n_problems", C.c_uint32), ("max_nodes", C.c_uint32), ("stop_at_goal", C.c_uint32),
         ("kernel", C.c_uint32), ("seed", C.c_uint64), ("first_problem_id", C.c_uint64),
-        ("device", C.c_int32), ("planner", C.c_uint32),
+        ("device", C.c_int32), ("planner", C.c_uint32), ("search_radius", C.c_double),
     ]
 
 
@@ -110,6 +110,7 @@ def lib():
         L.oxhip_rrt_batch_get_path.argtypes = [C.c_void_p, C.c_uint32, _dp, C.c_uint32, _u32p]
         L.oxhip_rrt_batch_get_goal_counts.argtypes = [C.c_void_p, _u32p, _i32p]
         L.oxhip_rrt_batch_get_goal_tree.argtypes = [C.c_void_p, C.c_uint32, _dp, _i32p, C.c_uint32, _u32p]
+        L.oxhip_rrt_batch_get_costs.argtypes = [C.c_void_p, C.c_uint32, _dp, C.c_uint32, _u32p]
         L.oxhip_rrt_batch_last_timing.argtypes = [C.c_void_p, _dp, _u32p, _u32p]
         L.oxhip_rrt_batch_enable_stamps.argtypes = [C.c_void_p, C.c_uint32]
         L.oxhip_rrt_batch_get_stamps.argtypes = [C.c_void_p, _u64p]
@@ -174,7 +175,7 @@ class RRTBatch:
 
     def __init__(self, dim, bounds, max_distance, goal_bias, n_problems, max_nodes=10000,
                  lvs_fraction=0.05, stop_at_goal=True, seed=0, first_problem_id=0, device=0,
-                 kernel=KERNEL_AUTO, planner=PLANNER_RRT):
+                 kernel=KERNEL_AUTO, planner=PLANNER_RRT, search_radius=0.0):
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
         cfg.dim = dim
@@ -188,6 +189,7 @@ class RRTBatch:
         cfg.stop_at_goal, cfg.kernel = int(bool(stop_at_goal)), kernel
         cfg.seed, cfg.first_problem_id, cfg.device = seed, first_problem_id, device
         cfg.planner = planner
+        cfg.search_radius = search_radius
         self.planner = planner
         self.dim, self.n_problems, self.max_nodes = dim, n_problems, max_nodes
         self._h = C.c_void_p()
@@ -246,6 +248,14 @@ class RRTBatch:
         parents = np.empty(n.value, dtype=np.int32)
         _check(lib().oxhip_rrt_batch_get_tree(self._h, problem, _p(states), _p(parents, _i32p), n.value, C.byref(n)))
         return states, parents
+
+    def costs(self, problem):
+        """RRT*: Node::cost of every node (rrt_star.rs:26)"""
+        n = C.c_uint32()
+        _check(lib().oxhip_rrt_batch_get_costs(self._h, problem, None, 0, C.byref(n)))
+        out = np.empty(n.value, dtype=np.float64)
+        _check(lib().oxhip_rrt_batch_get_costs(self._h, problem, _p(out), n.value, C.byref(n)))
+        return out
 
     def goal_counts(self):
         """RRTConnect: goal-tree sizes and the last goal-tree node of each solution"""

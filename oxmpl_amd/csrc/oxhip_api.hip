@@ -31,6 +31,8 @@ struct oxhip_rrt_batch {
     std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
     bool filt_dirty = true;
     DevBuf<double> tree_b;   // RRTConnect goal trees
+    DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
+    DevBuf<uint32_t> nb_idx;
     DevBuf<int32_t> parent;
     DevBuf<int32_t> parent_b;
     DevBuf<uint8_t> skip;
@@ -88,9 +90,11 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (!(cfg->max_distance > 0.0) || !std::isfinite(cfg->max_distance))
         return fail(OXHIP_ERR_BAD_ARG, "max_distance must be finite and > 0");
     if (cfg->kernel > OXHIP_KERNEL_PRUNED) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
-    if (cfg->planner > OXHIP_PLANNER_RRT_CONNECT) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
-    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
-        return fail(OXHIP_ERR_BAD_ARG, "RRTConnect runs on the stream kernel only");
+    if (cfg->planner > OXHIP_PLANNER_RRT_STAR) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
+    if (cfg->planner != OXHIP_PLANNER_RRT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
+        return fail(OXHIP_ERR_BAD_ARG, "RRTConnect / RRT* run on the stream kernel only");
+    if (cfg->planner == OXHIP_PLANNER_RRT_STAR && std::isnan(cfg->search_radius))
+        return fail(OXHIP_ERR_BAD_ARG, "search_radius is NaN");
     double fraction = cfg->lvs_fraction, res = 0.0;
     {
         int32_t sr = space_resolution(cfg->dim, cfg->bounds, fraction, res);
@@ -120,6 +124,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.first_problem_id = cfg->first_problem_id;
     dp.stop_at_goal = cfg->stop_at_goal ? 1 : 0;
     dp.t_steer = sqrt_le_threshold(cfg->max_distance);
+    dp.thr_search = sqrt_lt_threshold(cfg->search_radius);
 
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
@@ -133,6 +138,11 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         chk(b->tree_b.alloc((size_t)P * dim * cap));
         chk(b->parent_b.alloc((size_t)P * cap));
     }
+    if (cfg->planner == OXHIP_PLANNER_RRT_STAR) {
+        chk(b->cost.alloc((size_t)P * cap));
+        chk(b->nb_idx.alloc((size_t)P * cap));
+        chk(b->nb_dist.alloc((size_t)P * cap));
+    }
     chk(b->state.alloc(P));
     chk(b->goal_c.alloc((size_t)P * dim));
     chk(b->goal_thr.alloc(P));
@@ -143,10 +153,11 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     }
     dp.tree = b->tree.p; dp.parent = b->parent.p; dp.skip = b->skip.p; dp.state = b->state.p;
     dp.tree_b = b->tree_b.p; dp.parent_b = b->parent_b.p;
+    dp.cost = b->cost.p; dp.nb_idx = b->nb_idx.p; dp.nb_dist = b->nb_dist.p;
     dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p;
 
     uint32_t kind = cfg->kernel;
-    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT) kind = OXHIP_KERNEL_STREAM;
+    if (cfg->planner != OXHIP_PLANNER_RRT) kind = OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO) kind = resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_PRUNED && !pruned_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
@@ -254,6 +265,8 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
         HIP_TRY(hipMemcpy2DAsync(b->parent_b.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
                                  sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
     }
+    if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR)   // start node: cost 0.0 (rrt_star.rs:163-167)
+        HIP_TRY(hipMemsetAsync(b->cost.p, 0, (size_t)P * cap * sizeof(double), b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->is_setup = true;
     return OXHIP_OK;
@@ -353,7 +366,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
     if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");  // rrt.rs:160-163
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
-    if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT && freeze) return fail(OXHIP_ERR_BAD_ARG, "freeze is for the RRT planner");
+    if (b->cfg.planner != OXHIP_PLANNER_RRT && freeze) return fail(OXHIP_ERR_BAD_ARG, "freeze is for the RRT planner");
     if ((st = refresh_filter(b)) != OXHIP_OK) return st;
     const bool has_timeout = timeout_s > 0.0 && std::isfinite(timeout_s);
     const auto t0 = std::chrono::steady_clock::now();
@@ -371,6 +384,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         b->dp.freeze = freeze ? 1 : 0;
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
         if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
+        else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) launch_rrt_star(b->dp, b->stream);
         else if (b->kernel_kind == OXHIP_KERNEL_PRUNED) launch_rrt_pruned(b->dp, b->stream);
         else if (b->kernel_kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
         else launch_rrt_stream(b->dp, b->stream);
@@ -548,6 +562,24 @@ int32_t oxhip_rrt_batch_get_goal_tree(oxhip_rrt_batch* b, uint32_t problem, doub
         for (uint32_t i = 0; i < n; ++i)
             for (uint32_t k = 0; k < dim; ++k) states_out[(size_t)i * dim + k] = soa[(size_t)k * n + i];
     if (parents_out) std::memcpy(parents_out, par.data(), (size_t)n * sizeof(int32_t));
+    return OXHIP_OK;
+}
+
+int32_t oxhip_rrt_batch_get_costs(oxhip_rrt_batch* b, uint32_t problem, double* costs, uint32_t cap_nodes, uint32_t* n_nodes) {
+    if (!b || !n_nodes) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (!b->is_setup) return fail(OXHIP_ERR_PLANNER_UNINITIALISED, "setup() was not called");
+    if (b->cfg.planner != OXHIP_PLANNER_RRT_STAR) return fail(OXHIP_ERR_BAD_ARG, "not an RRT* batch");
+    if (problem >= b->cfg.n_problems) return fail(OXHIP_ERR_BAD_ARG, "problem index out of range");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    std::vector<ProblemState> states;
+    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    const uint32_t n = states[problem].n_nodes;
+    *n_nodes = n;
+    if (!costs) return OXHIP_OK;
+    if (n > cap_nodes) return fail(OXHIP_ERR_CAPACITY, "cost buffer too small");
+    HIP_TRY(hipMemcpyAsync(costs, b->cost.p + (size_t)problem * b->dp.cap, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
     return OXHIP_OK;
 }
 

@@ -27,6 +27,9 @@ void launch_rng_u64(uint64_t seed, uint64_t stream, uint32_t n, uint64_t* out, h
 // rrt_connect.hip: RRTConnect (rrt_connect.rs), one 256-thread workgroup per problem, trees streamed from HBM/L2
 void launch_rrt_connect(const DevParams& p, hipStream_t stream);
 
+// rrt_star.hip: RRT* (rrt_star.rs), one 256-thread workgroup per problem
+void launch_rrt_star(const DevParams& p, hipStream_t stream);
+
 // rrt_resident.hip
 // true when a register-resident instantiation exists for (dim, cap)
 bool resident_supported(uint32_t dim, uint32_t cap);

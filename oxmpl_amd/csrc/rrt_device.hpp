@@ -63,6 +63,11 @@ struct DevParams {
     double t_steer;         // largest d2 with sqrt(d2) <= max_distance: steer iff d2 > t_steer (exact)
     const double* sph_filt; // [n_spheres] conservative filter: d2(centre, segment midpoint) > filt => sphere cannot be hit
     uint64_t* dbg;          // optional [16] cycle stamps of workgroup 0 (diagnostic build of the resident kernel)
+    // RRT* only (rrt_star.hip)
+    double* cost;           // [P][cap] cost-to-come of every node (Node::cost, rrt_star.rs:26)
+    uint32_t* nb_idx;       // [P][cap] scratch: find_neighbours' result of the current iteration
+    double* nb_dist;        // [P][cap] scratch: distance(q_new, neighbour)
+    double thr_search;      // largest d2 with sqrt(d2) < search_radius (strict, rrt_star.rs:125)
     // PRM only (prm_kernels.hip): the midpoint filter's inputs for motions of any length
     const double* sph_r;    // [n_spheres] radii as given
     double filt_abs;        // 1e-9 * largest coordinate magnitude in play (absolute rounding margin)

@@ -1,0 +1,153 @@
+"""GPU parity tests of RRT* (planner kind 2, rrt_star.hip) through the C ABI against the CPU oracle
+(orc_rrts_*) and the golden fixtures: node count, iteration count, per-iteration checksum (nearest, q_new,
+verdict, chosen parent, cost bits, rewired count and index sum), tree bits, parents after rewiring, costs, path.
+PARITY UNPINNED against oxmpl itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import unhex, bits, params_spheres, params_boxes
+
+pytestmark = pytest.mark.gpu
+
+from oxmpl_amd import capi  # noqa: E402
+from oracle import oracle_py as orc  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def star_golden():
+    with open(os.path.join(ROOT, "tests", "golden", "rrt_star_golden.json")) as f:
+        return json.load(f)
+
+
+def make_oracle(P, seed, pid, stop=True, max_nodes=None):
+    o = orc.OracleRRTStar(P["dim"], P["bounds"], P["max_distance"], P["goal_bias"], P["search_radius"], P["fraction"],
+                          max_nodes or P["max_nodes"], stop, seed, pid)
+    if P["spheres"]:
+        o.set_spheres(*params_spheres(P))
+    if P["boxes"]:
+        o.set_boxes(*params_boxes(P))
+    o.setup(P["start"], P["goal_c"], P["goal_r"])
+    return o
+
+
+def make_gpu(P, n_problems, seed, first_pid, stop=True, max_nodes=None):
+    g = capi.RRTBatch(P["dim"], P["bounds"], P["max_distance"], P["goal_bias"], n_problems, max_nodes or P["max_nodes"],
+                      P["fraction"], stop, seed, first_pid, 0, capi.KERNEL_AUTO, capi.PLANNER_RRT_STAR, P["search_radius"])
+    if P["spheres"]:
+        g.set_spheres(*params_spheres(P))
+    if P["boxes"]:
+        g.set_boxes(*params_boxes(P))
+    g.setup(P["start"], P["goal_c"], P["goal_r"])
+    return g
+
+
+def assert_same(g, p, o, c=None):
+    c = c or g.counts()
+    assert int(c["nodes"][p]) == o.num_nodes
+    assert int(c["iterations"][p]) == o.iterations
+    assert int(c["accepted"][p]) == o.accepted
+    assert int(c["checksum"][p]) == o.checksum
+    assert int(c["goal_node"][p]) == o.goal_node
+    gs, gp = g.tree(p)
+    os_, op = o.tree()
+    assert np.array_equal(bits(gs), bits(os_)) and np.array_equal(gp, op)
+    assert np.array_equal(bits(g.costs(p)), bits(o.costs()))
+    gpath, opath = g.path(p), o.path()
+    assert gpath.shape == opath.shape and np.array_equal(bits(gpath), bits(opath))
+
+
+@pytest.mark.parametrize("key", ["wall", "wall_ref", "config1", "config2"])
+def test_rrt_star_golden_scenes(star_golden, key):
+    P = star_golden[key]["params"]
+    stop = key != "config2"
+    for r in star_golden[key]["runs"]:
+        g = make_gpu(P, 1, r["seed"], r["pid"], stop)
+        st = g.solve(P["max_iterations"])
+        c = g.counts()
+        assert int(c["nodes"][0]) == r["n"] and int(c["iterations"][0]) == r["iterations"]
+        assert "%016x" % int(c["checksum"][0]) == r["checksum"] and int(c["goal_node"][0]) == r["goal_node"]
+        assert (st[0] == capi.OK) == (r["goal_node"] >= 0)
+        gs, gp = g.tree(0)
+        head = np.array([[unhex(v) for v in row] for row in r["states"]])
+        assert np.array_equal(bits(gs[:len(head)]), bits(head))
+        assert list(gp) == r["parents"]
+        assert np.array_equal(bits(g.costs(0)), bits(np.array([unhex(v) for v in r["cost"]])))
+        want = np.array([[unhex(v) for v in row] for row in r["path"]]).reshape(-1, P["dim"])
+        got = g.path(0)
+        assert got.shape == want.shape and np.array_equal(bits(got), bits(want))
+        o = make_oracle(P, r["seed"], r["pid"], stop)
+        o.solve(P["max_iterations"])
+        assert_same(g, 0, o, c)
+        g.close()
+
+
+def test_rrt_star_batch_of_problems_in_the_sphere_field(star_golden):
+    """48 problems of the config-2 field, 1500 iterations each, grown in two solve calls (resume)"""
+    P = star_golden["config2"]["params"]
+    n_prob = 48
+    g = make_gpu(P, n_prob, 42, 100, stop=False)
+    g.solve(700)
+    g.solve(800)
+    c = g.counts()
+    for p in range(0, n_prob, 5):
+        o = make_oracle(P, 42, 100 + p, stop=False)
+        o.solve(1500)
+        assert_same(g, p, o, c)
+    assert int(c["iterations"].min()) == 1500
+
+
+@pytest.mark.parametrize("radius", [0.0, 0.3, 2.5, float("inf")])
+def test_rrt_star_search_radius_extremes(star_golden, radius):
+    """radius 0: no neighbour ever (RRT with costs); inf: every node is a neighbour of every new node"""
+    P = dict(star_golden["config1"]["params"], search_radius=radius, max_nodes=400)
+    g = make_gpu(P, 4, 9, 0, stop=False)
+    g.solve(10 ** 6)
+    c = g.counts()
+    assert (c["stop_reason"] == capi.STOP_NODES).all() and (c["nodes"] == 400).all()
+    for p in range(4):
+        o = make_oracle(P, 9, p, stop=False)
+        o.solve(10 ** 6)
+        assert o.num_nodes == 400
+        assert_same(g, p, o, c)
+    if radius == 0.0:
+        # without neighbours the tree is exactly RRT's
+        r = orc.OracleRRT(P["dim"], P["bounds"], P["max_distance"], P["goal_bias"], P["fraction"], 400, False, 9, 0)
+        r.set_spheres(*params_spheres(P))
+        r.setup(P["start"], P["goal_c"], P["goal_r"])
+        r.solve(10 ** 6)
+        gs, gp = g.tree(0)
+        rs, rp = r.tree()
+        assert np.array_equal(bits(gs), bits(rs)) and np.array_equal(gp, rp)
+
+
+def test_rrt_star_rewiring_shortens_costs(star_golden):
+    """a property of the algorithm, checked on the device result: with a useful search radius the goal node's
+    cost-to-come is not worse than without rewiring / parent choice (radius 0) on the same sample stream"""
+    base = dict(star_golden["wall"]["params"], max_nodes=3000)
+    res = {}
+    for radius in (0.0, 1.0):
+        P = dict(base, search_radius=radius)
+        g = make_gpu(P, 8, 5, 0, stop=False)
+        g.solve(10 ** 6)
+        c = g.counts()
+        assert (c["goal_node"] >= 0).all()
+        res[radius] = np.array([g.costs(p)[int(c["goal_node"][p])] for p in range(8)])
+    assert res[1.0].mean() < res[0.0].mean()
+
+
+def test_rrt_star_argument_validation():
+    with pytest.raises(capi.OxhipError) as ei:
+        capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.5, 0.05, 1, 100, planner=capi.PLANNER_RRT_STAR, search_radius=float("nan"))
+    assert ei.value.status == capi.ERR_BAD_ARG
+    with pytest.raises(capi.OxhipError) as ei:
+        capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.5, 0.05, 1, 100, planner=capi.PLANNER_RRT_STAR, kernel=capi.KERNEL_RESIDENT)
+    assert ei.value.status == capi.ERR_BAD_ARG
+    g = capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.5, 0.05, 1, 100, planner=capi.PLANNER_RRT, search_radius=1.0)
+    g.setup([0.1, 0.1], [0.9, 0.9], 0.1)
+    with pytest.raises(capi.OxhipError):
+        g.costs(0)          # not an RRT* batch
