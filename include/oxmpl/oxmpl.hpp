@@ -192,6 +192,7 @@ class RRT {
         cfg.first_problem_id = problem_id;
         cfg.device = device;
         cfg.planner = planner_kind();
+        cfg.search_radius = search_radius_value();
         if ((last_status_ = oxhip_rrt_batch_create(&cfg, &batch_)) != OXHIP_OK) return;
         std::vector<double> c, r, lo, hi;
         for (auto& s : vc_->spheres()) { c.insert(c.end(), s.centre.begin(), s.centre.end()); r.push_back(s.radius); }
@@ -239,6 +240,8 @@ class RRT {
 
   protected:
     virtual uint32_t planner_kind() const { return OXHIP_PLANNER_RRT; }
+    virtual double search_radius_value() const { return 0.0; }
+    oxhip_rrt_batch* batch() const { return batch_; }
 
   private:
     void reset() {
@@ -258,6 +261,27 @@ class RRTConnect : public RRT {
 
   protected:
     uint32_t planner_kind() const override { return OXHIP_PLANNER_RRT_CONNECT; }
+};
+
+// RRTStar (rrt_star.rs:39-52): RRT with choose-parent and rewire inside `search_radius`.
+class RRTStar : public RRT {
+  public:
+    double search_radius;
+    RRTStar(double max_distance_, double goal_bias_, double search_radius_)   // rrt_star.rs:68-77
+        : RRT(max_distance_, goal_bias_), search_radius(search_radius_) {}
+
+    // Node::cost (rrt_star.rs:26) of every node, in node order
+    std::vector<double> costs() const {
+        uint32_t n = 0;
+        if (!batch() || oxhip_rrt_batch_get_costs(batch(), 0, nullptr, 0, &n) != OXHIP_OK) return {};
+        std::vector<double> c(n);
+        if (oxhip_rrt_batch_get_costs(batch(), 0, c.data(), n, &n) != OXHIP_OK) return {};
+        return c;
+    }
+
+  protected:
+    uint32_t planner_kind() const override { return OXHIP_PLANNER_RRT_STAR; }
+    double search_radius_value() const override { return search_radius; }
 };
 
 // PRM (prm.rs:48-57): roadmap built and queried on the GPU.

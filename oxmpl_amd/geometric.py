@@ -44,7 +44,7 @@ class RRT:
         try:
             b = capi.RRTBatch(pd.space.dimension, pd.space.bounds, self.max_distance, self.goal_bias, 1,
                               lvs_fraction=pd.space.longest_valid_segment_fraction, stop_at_goal=True,
-                              planner=self._PLANNER, **self._opts)
+                              planner=self._PLANNER, search_radius=getattr(self, "search_radius", 0.0), **self._opts)
         except capi.OxhipError as e:
             if e.status in (capi.ERR_UNBOUNDED, capi.ERR_ZERO_VOLUME, capi.ERR_BAD_ARG):
                 raise ValueError(str(e)) from None
@@ -85,6 +85,21 @@ class RRTConnect(RRT):
     @property
     def num_nodes(self):
         return int(self._batch.counts()["nodes"][0]) + int(self._batch.goal_counts()["nodes"][0])
+
+
+class RRTStar(RRT):
+    """oxmpl_py.geometric.RRTStar (oxmpl-py/src/geometric/rrt_star.rs:30-140; planner:
+    oxmpl/src/geometric/planners/rrt_star.rs): RRTStar(max_distance, goal_bias, search_radius, problem_definition)."""
+    _PLANNER = capi.PLANNER_RRT_STAR
+
+    def __init__(self, max_distance, goal_bias, search_radius, problem_definition, **opts):
+        super().__init__(max_distance, goal_bias, problem_definition, **opts)
+        self.search_radius = float(search_radius)
+
+    def path_cost(self):
+        """Node::cost of the goal node (rrt_star.rs:26)"""
+        g = int(self._batch.counts()["goal_node"][0])
+        return float(self._batch.costs(0)[g]) if g >= 0 else float("inf")
 
 
 class PRM:

@@ -11,6 +11,7 @@
 using namespace oxmpl::base;
 using oxmpl::geometric::RRT;
 using oxmpl::geometric::RRTConnect;
+using oxmpl::geometric::RRTStar;
 
 // rrt_rvss_tests.rs:17-36
 struct WallObstacleChecker : StateValidityChecker {
@@ -114,6 +115,18 @@ int main() {
     CHECK(space->distance(pathc.states.front(), start_state) < 1e-9, "RRTConnect path should start at the start state");
     CHECK(space->distance(pathc.states.back(), goal_definition->target()) <= goal_definition->radius(), "RRTConnect path should end in the goal region");
     CHECK(is_path_valid(pathc, *space, pc), "The RRTConnect path was found to be invalid.");
+    // oxmpl/tests/rrt_star_rvss_tests.rs: the same scene through RRTStar::new(0.5, 0.0, 0.25)
+    RRTStar ps(0.5, 0.0, 0.25);
+    ps.setup(problem_definition, validity_checker);
+    CHECK(ps.last_status() == OXHIP_OK, "RRTStar setup");
+    auto rs = ps.solve(std::chrono::seconds(5));
+    CHECK(rs.is_ok(), "RRTStar failed to find a solution when one should exist.");
+    const Path& paths = rs.unwrap();
+    CHECK(!paths.states.empty(), "RRTStar path should not be empty");
+    CHECK(space->distance(paths.states.front(), start_state) < 1e-9, "RRTStar path should start at the start state");
+    CHECK(space->distance(paths.states.back(), goal_definition->target()) <= goal_definition->radius(), "RRTStar path should end in the goal region");
+    CHECK(is_path_valid(paths, *space, ps), "The RRTStar path was found to be invalid.");
+    CHECK(ps.costs().size() == ps.num_nodes() && ps.costs()[0] == 0.0, "RRTStar costs");
     std::printf("RRT planner test passed!\n");
     return 0;
 }
