@@ -20,7 +20,7 @@ STOP_GOAL, STOP_ITERATIONS, STOP_NODES, STOP_TIMEOUT = 0, 1, 2, 3
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("rrt_oracle.c", "rrt_oracle.h", "prm_oracle.c", "prm_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("rrt_oracle.c", "rrt_oracle.h", "prm_oracle.c", "prm_oracle.h", "se2_oracle.c", "se2_oracle.h", "Makefile")]
     if (not force) and os.path.exists(_LIB_PATH) and all(
             os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src):
         return _LIB_PATH
@@ -115,6 +115,41 @@ def lib():
         L.orc_rrts_base.restype = C.c_void_p
         L.orc_rrts_get_costs.argtypes = [C.c_void_p, _dp]
         L.orc_rrts_get_costs.restype = None
+        for name, nargs in (("orc_so2_normalise", 1), ("orc_so2_distance", 2), ("orc_so2_interpolate", 3)):
+            getattr(L, name).argtypes = [C.c_double] * nargs
+            getattr(L, name).restype = C.c_double
+        L.orc_se2_distance.argtypes = [_dp, _dp]
+        L.orc_se2_distance.restype = C.c_double
+        L.orc_se2_interpolate.argtypes = [_dp, _dp, C.c_double, _dp]
+        L.orc_se2_interpolate.restype = None
+        L.orc_se2_extent.argtypes = [_dp]
+        L.orc_se2_extent.restype = C.c_double
+        L.orc_point_segment_distance.argtypes = [C.c_double, C.c_double, _dp]
+        L.orc_point_segment_distance.restype = C.c_double
+        L.orc_se2c_new.argtypes = [_dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_uint64,
+                                   C.c_uint64, C.POINTER(C.c_int)]
+        L.orc_se2c_new.restype = C.c_void_p
+        L.orc_se2c_free.argtypes = [C.c_void_p]
+        L.orc_se2c_set_segments.argtypes = [C.c_void_p, _dp, C.c_uint32, C.c_double]
+        L.orc_se2c_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.orc_se2c_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
+        L.orc_se2c_num_nodes.argtypes = [C.c_void_p, C.c_int]
+        L.orc_se2c_num_nodes.restype = C.c_uint32
+        for name in ("orc_se2c_iterations", "orc_se2c_checksum"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint64
+        L.orc_se2c_end_node.argtypes = [C.c_void_p, C.c_int]
+        L.orc_se2c_end_node.restype = C.c_int32
+        L.orc_se2c_stop_reason.argtypes = [C.c_void_p]
+        L.orc_se2c_stop_reason.restype = C.c_int32
+        L.orc_se2c_get_tree.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int32)]
+        L.orc_se2c_get_tree.restype = None
+        L.orc_se2c_get_path.argtypes = [C.c_void_p, _dp, C.c_uint32]
+        L.orc_se2c_get_path.restype = C.c_uint32
+        L.orc_se2c_is_valid.argtypes = [C.c_void_p, _dp]
+        L.orc_se2c_check_motion.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_se2c_theta_bounds.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_se2c_theta_bounds.restype = None
         _u32p = C.POINTER(C.c_uint32)
         L.orc_prm_new.argtypes = [C.c_uint32, _dp, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_uint64,
                                   C.POINTER(C.c_int)]
@@ -483,3 +518,87 @@ class OracleRRTStar(OracleRRT):
         out = np.empty(self.num_nodes, dtype=np.float64)
         lib().orc_rrts_get_costs(self.hs, out.ctypes.data_as(_dp))
         return out
+
+
+def se2_distance(a, b):
+    a, pa = _d(a)
+    b, pb = _d(b)
+    return lib().orc_se2_distance(pa, pb)
+
+
+def se2_interpolate(a, b, t):
+    a, pa = _d(a)
+    b, pb = _d(b)
+    out = np.zeros(3)
+    lib().orc_se2_interpolate(pa, pb, t, out.ctypes.data_as(_dp))
+    return out
+
+
+def point_segment_distance(px, py, seg):
+    s, ps = _d(seg)
+    return lib().orc_point_segment_distance(px, py, ps)
+
+
+class OracleSE2Connect:
+    """RRTConnect (rrt_connect.rs) over the build-defined SE(2) space with a segment-soup checker (oracle/se2_oracle.h)"""
+    dim = 3
+
+    def __init__(self, bounds_xy, theta_bounds, max_distance, goal_bias, lvs_fraction=0.05, max_nodes=10000, seed=0,
+                 problem_id=0):
+        b, pb = _d(np.asarray(bounds_xy, dtype=np.float64).reshape(-1))
+        st = C.c_int()
+        self.h = lib().orc_se2c_new(pb, theta_bounds[0], theta_bounds[1], max_distance, goal_bias, lvs_fraction, max_nodes,
+                                    seed, problem_id, C.byref(st))
+        self.create_status = st.value
+        if not self.h:
+            raise ValueError("orc_se2c_new failed with status %d" % st.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_se2c_free(self.h)
+            self.h = None
+
+    def set_segments(self, segs, clearance):
+        s, ps = _d(np.asarray(segs, dtype=np.float64).reshape(-1, 4))
+        lib().orc_se2c_set_segments(self.h, ps, s.shape[0], clearance)
+
+    def setup(self, start, goal, goal_radius):
+        s, ps = _d(start)
+        g, pg = _d(goal)
+        return lib().orc_se2c_setup(self.h, ps, pg, goal_radius)
+
+    def solve(self, max_iterations, timeout_s=float("inf")):
+        return lib().orc_se2c_solve(self.h, max_iterations, timeout_s)
+
+    def num_nodes(self, which):
+        return lib().orc_se2c_num_nodes(self.h, which)
+
+    iterations = property(lambda self: lib().orc_se2c_iterations(self.h))
+    checksum = property(lambda self: lib().orc_se2c_checksum(self.h))
+    stop_reason = property(lambda self: lib().orc_se2c_stop_reason(self.h))
+
+    def end_node(self, which):
+        return lib().orc_se2c_end_node(self.h, which)
+
+    def tree(self, which):
+        n = self.num_nodes(which)
+        states = np.empty((n, 3), dtype=np.float64)
+        parents = np.empty(n, dtype=np.int32)
+        lib().orc_se2c_get_tree(self.h, which, states.ctypes.data_as(_dp), parents.ctypes.data_as(C.POINTER(C.c_int32)))
+        return states, parents
+
+    def path(self):
+        n = lib().orc_se2c_get_path(self.h, None, 0)
+        out = np.empty((n, 3), dtype=np.float64)
+        if n:
+            lib().orc_se2c_get_path(self.h, out.ctypes.data_as(_dp), n)
+        return out
+
+    def is_valid(self, s):
+        a, pa = _d(s)
+        return bool(lib().orc_se2c_is_valid(self.h, pa))
+
+    def check_motion(self, a, b):
+        a, pa = _d(a)
+        b, pb = _d(b)
+        return bool(lib().orc_se2c_check_motion(self.h, pa, pb))
