@@ -61,6 +61,15 @@ typedef enum oxhip_planner_kind {
     OXHIP_PLANNER_RRT_STAR = 2     /* geometric::RRTStar     oxmpl/src/geometric/planners/rrt_star.rs (stream kernel only) */
 } oxhip_planner_kind;
 
+/* State space of a batch.  oxmpl has RealVectorStateSpace, SO2StateSpace and SO3StateSpace; SE(2) is not in the
+ * reference (docs/BACKLOG.md:12-14) and is assembled here from the first two (see rrt_connect_se2.hip):
+ * state (x, y, theta), distance = 1.0 * d_xy + 0.5 * d_theta, extent = extent_xy + 0.5 * PI. */
+typedef enum oxhip_space_kind {
+    OXHIP_SPACE_REAL_VECTOR = 0,  /* RealVectorStateSpace(dim)  oxmpl/src/base/spaces/real_vector_state_space.rs */
+    OXHIP_SPACE_SE2 = 1           /* R^2 x SO(2): dim must be 3, bounds = (x), (y), (theta: clamped to [-PI, PI]);
+                                     planner must be OXHIP_PLANNER_RRT_CONNECT; validity = oxhip_rrt_batch_set_segments */
+} oxhip_space_kind;
+
 typedef enum oxhip_kernel_kind {
     OXHIP_KERNEL_AUTO = 0,      /* resident when the tree fits the register file, else streaming */
     OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
@@ -88,6 +97,8 @@ typedef struct oxhip_rrt_config {
     uint32_t planner;                   /* oxhip_planner_kind: 0 = RRT (rrt.rs), 1 = RRTConnect (rrt_connect.rs), 2 = RRT* */
     double   search_radius;             /* RRTStar::search_radius (rrt_star.rs:45): neighbours are the nodes with
                                            distance < search_radius (strict); ignored by the other planners */
+    uint32_t space;                     /* oxhip_space_kind */
+    uint32_t reserved;                  /* 0 */
 } oxhip_rrt_config;
 
 typedef struct oxhip_rrt_batch oxhip_rrt_batch;
@@ -112,6 +123,12 @@ int32_t oxhip_rrt_batch_set_spheres(oxhip_rrt_batch* b, const double* centres /*
                                     const double* radii /*[n]*/, uint32_t n);
 int32_t oxhip_rrt_batch_set_boxes(oxhip_rrt_batch* b, const double* lo /*[n][dim]*/,
                                   const double* hi /*[n][dim]*/, uint32_t n);
+
+/* SE(2) batches only.  The checker of BASELINE.json configs[3]: a disc robot of radius `clearance` among n line
+ * segments (ax, ay, bx, by) -- a state is valid iff its (x, y) is farther than `clearance` from every segment
+ * (strict; the heading does not enter).  Replaces any earlier segment set. */
+int32_t oxhip_rrt_batch_set_segments(oxhip_rrt_batch* b, const double* segments /*[n][4]*/, uint32_t n,
+                                     double clearance);
 
 /* Planner::setup (rrt.rs:140-156) for every problem: clears the tree, pushes start_states[0]
  * (validity of the start is NOT checked, as in the reference), resets counters and the RNG
@@ -200,6 +217,11 @@ int32_t oxhip_rrt_batch_check_motion(oxhip_rrt_batch* b, const double* from, con
  * op: 0 sqrt(a), 1 a/b, 2 ceil(a), 3 a + (b - a) * t (t = c[i], unfused), 4 (a-b)*(a-b) */
 int32_t oxhip_f64_op_batch(int32_t device, uint32_t op, const double* a, const double* b,
                            const double* c, uint32_t n, double* out);
+/* SO(2) / SE(2) arithmetic self-test hooks, n rows of (x, y, theta):
+ * op 0: out[i] = (se2_distance(a_i, b_i), so2_normalise(a_i.theta), so2_distance(a_i.theta, b_i.theta))
+ * op 1: out[i] = se2_interpolate(a_i, b_i, t[i])        (so2_state_space.rs:97-122, so2_state.rs:33-37) */
+int32_t oxhip_se2_op_batch(int32_t device, uint32_t op, const double* a, const double* b, const double* t, uint32_t n,
+                           double* out);
 /* device RNG self-test: the first n u64 words of the (seed, stream) ChaCha12 stream */
 int32_t oxhip_rng_u64_batch(int32_t device, uint64_t seed, uint64_t stream, uint32_t n, uint64_t* out);
 

@@ -20,18 +20,19 @@ ERR_BAD_ARG, ERR_UNBOUNDED, ERR_ZERO_VOLUME, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVIC
 STOP_NONE, STOP_GOAL, STOP_ITERATIONS, STOP_NODES, STOP_TIMEOUT = -1, 0, 1, 2, 3
 KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT, KERNEL_PRUNED = 0, 1, 2, 3
 PLANNER_RRT, PLANNER_RRT_CONNECT, PLANNER_RRT_STAR = 0, 1, 2
+SPACE_REAL_VECTOR, SPACE_SE2 = 0, 1
 
 # every symbol include/oxmpl_hip.h declares (tests check the library exports them all)
 EXPORTS = [
     "oxhip_abi_version", "oxhip_status_string", "oxhip_last_error_string", "oxhip_device_count",
     "oxhip_rrt_batch_create", "oxhip_rrt_batch_destroy", "oxhip_rrt_batch_set_spheres",
-    "oxhip_rrt_batch_set_boxes", "oxhip_rrt_batch_setup", "oxhip_rrt_batch_set_tree", "oxhip_rrt_batch_solve",
+    "oxhip_rrt_batch_set_boxes", "oxhip_rrt_batch_set_segments", "oxhip_rrt_batch_setup", "oxhip_rrt_batch_set_tree", "oxhip_rrt_batch_solve",
     "oxhip_rrt_batch_get_counts", "oxhip_rrt_batch_get_tree", "oxhip_rrt_batch_get_path",
     "oxhip_rrt_batch_get_goal_counts", "oxhip_rrt_batch_get_goal_tree", "oxhip_rrt_batch_get_costs",
     "oxhip_rrt_batch_last_timing", "oxhip_rrt_batch_enable_stamps", "oxhip_rrt_batch_get_stamps",
     "oxhip_nn_argmin_batch", "oxhip_distance_batch",
     "oxhip_interpolate_batch", "oxhip_rrt_batch_is_valid", "oxhip_rrt_batch_check_motion",
-    "oxhip_f64_op_batch", "oxhip_rng_u64_batch",
+    "oxhip_f64_op_batch", "oxhip_se2_op_batch", "oxhip_rng_u64_batch",
     "oxhip_prm_create", "oxhip_prm_destroy", "oxhip_prm_set_spheres", "oxhip_prm_set_boxes", "oxhip_prm_setup",
     "oxhip_prm_set_problem", "oxhip_prm_construct_roadmap", "oxhip_prm_get_sizes", "oxhip_prm_get_roadmap",
     "oxhip_prm_solve", "oxhip_prm_get_query_sets", "oxhip_prm_last_timing",
@@ -45,6 +46,7 @@ class Config(C.Structure):
         ("n_problems", C.c_uint32), ("max_nodes", C.c_uint32), ("stop_at_goal", C.c_uint32),
         ("kernel", C.c_uint32), ("seed", C.c_uint64), ("first_problem_id", C.c_uint64),
         ("device", C.c_int32), ("planner", C.c_uint32), ("search_radius", C.c_double),
+        ("space", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -102,6 +104,8 @@ def lib():
         L.oxhip_rrt_batch_destroy.argtypes = [C.c_void_p]
         L.oxhip_rrt_batch_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
         L.oxhip_rrt_batch_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
+        L.oxhip_rrt_batch_set_segments.argtypes = [C.c_void_p, _dp, C.c_uint32, C.c_double]
+        L.oxhip_se2_op_batch.argtypes = [C.c_int32, C.c_uint32, _dp, _dp, _dp, C.c_uint32, _dp]
         L.oxhip_rrt_batch_setup.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.oxhip_rrt_batch_set_tree.argtypes = [C.c_void_p, C.c_uint32, _dp, _i32p, C.c_uint32]
         L.oxhip_rrt_batch_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.c_uint32, _i32p]
@@ -175,7 +179,7 @@ class RRTBatch:
 
     def __init__(self, dim, bounds, max_distance, goal_bias, n_problems, max_nodes=10000,
                  lvs_fraction=0.05, stop_at_goal=True, seed=0, first_problem_id=0, device=0,
-                 kernel=KERNEL_AUTO, planner=PLANNER_RRT, search_radius=0.0):
+                 kernel=KERNEL_AUTO, planner=PLANNER_RRT, search_radius=0.0, space=SPACE_REAL_VECTOR):
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
         cfg.dim = dim
@@ -190,6 +194,7 @@ class RRTBatch:
         cfg.seed, cfg.first_problem_id, cfg.device = seed, first_problem_id, device
         cfg.planner = planner
         cfg.search_radius = search_radius
+        cfg.space = space
         self.planner = planner
         self.dim, self.n_problems, self.max_nodes = dim, n_problems, max_nodes
         self._h = C.c_void_p()
@@ -211,6 +216,11 @@ class RRTBatch:
         lo = _f64(lo).reshape(-1, self.dim)
         hi = _f64(hi, lo.shape)
         _check(lib().oxhip_rrt_batch_set_boxes(self._h, _p(lo), _p(hi), lo.shape[0]))
+
+    def set_segments(self, segments, clearance):
+        """SE(2) batches: the segment-soup checker (disc robot of radius `clearance`)"""
+        s = _f64(segments).reshape(-1, 4)
+        _check(lib().oxhip_rrt_batch_set_segments(self._h, _p(s), s.shape[0], clearance))
 
     def setup(self, starts, goal_centres, goal_radii):
         P = self.n_problems
@@ -353,6 +363,15 @@ def f64_op_batch(op, a, b=None, c=None, device=0):
 def rng_u64_batch(seed, stream, n, device=0):
     out = np.empty(n, dtype=np.uint64)
     _check(lib().oxhip_rng_u64_batch(device, seed, stream, n, _p(out, _u64p)))
+    return out
+
+
+def se2_op_batch(op, a, b, t=None, device=0):
+    """op 0: rows (se2_distance, so2_normalise(a.theta), so2_distance(a.theta, b.theta)); op 1: se2_interpolate"""
+    a, b = _f64(a).reshape(-1, 3), _f64(b).reshape(-1, 3)
+    out = np.empty_like(a)
+    tt = None if t is None else _f64(t).reshape(-1)
+    _check(lib().oxhip_se2_op_batch(device, op, _p(a), _p(b), None if tt is None else _p(tt), a.shape[0], _p(out)))
     return out
 
 

@@ -31,6 +31,7 @@ struct oxhip_rrt_batch {
     std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
     bool filt_dirty = true;
     DevBuf<double> tree_b;   // RRTConnect goal trees
+    DevBuf<double> segs;            // SE(2): segment soup
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
     DevBuf<uint32_t> nb_idx;
     DevBuf<int32_t> parent;
@@ -96,7 +97,28 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR && std::isnan(cfg->search_radius))
         return fail(OXHIP_ERR_BAD_ARG, "search_radius is NaN");
     double fraction = cfg->lvs_fraction, res = 0.0;
-    {
+    double th_lo = 0.0, th_hi = 0.0;
+    if (cfg->space > OXHIP_SPACE_SE2) return fail(OXHIP_ERR_BAD_ARG, "unknown space kind");
+    if (cfg->space == OXHIP_SPACE_SE2) {
+        if (cfg->dim != 3) return fail(OXHIP_ERR_BAD_ARG, "SE(2) states are (x, y, theta): dim must be 3");
+        if (cfg->planner != OXHIP_PLANNER_RRT_CONNECT) return fail(OXHIP_ERR_BAD_ARG, "SE(2) is built for RRTConnect only");
+        // SO2StateSpace::new (so2_state_space.rs:57-72): lo >= hi is InvalidBound; bounds clamped to [-PI, PI]
+        const double pi = 3.14159265358979323846;
+        th_lo = cfg->bounds[4]; th_hi = cfg->bounds[5];
+        if (!(th_lo < th_hi)) return fail(OXHIP_ERR_ZERO_VOLUME, "theta: lower bound >= upper bound");
+        th_lo = th_lo > -pi ? th_lo : -pi;
+        th_hi = th_hi < pi ? th_hi : pi;
+        // extent = extent_xy + 0.5 * PI (so2_state_space.rs:78-80); lvsl = extent * fraction; res = lvsl * 0.1
+        int32_t sr = space_resolution(2, cfg->bounds, fraction, res);
+        if (sr != OXHIP_OK) return sr;
+        const double lvsl_xy10 = res;          // (extent_xy * fraction) * 0.1: recompute from the extent itself
+        (void)lvsl_xy10;
+        double acc = 0.0;
+        for (uint32_t k = 0; k < 2; ++k) { double w = cfg->bounds[2 * k + 1] - cfg->bounds[2 * k]; double sq = w * w; acc = acc + sq; }
+        const double extent = std::sqrt(acc) + 0.5 * pi;
+        const double lvsl = extent * fraction;
+        res = lvsl * 0.1;
+    } else {
         int32_t sr = space_resolution(cfg->dim, cfg->bounds, fraction, res);
         if (sr != OXHIP_OK) return sr;
     }
@@ -117,6 +139,8 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         dp.hi[k] = cfg->bounds[2 * k + 1];
         dp.scale[k] = dp.hi[k] - dp.lo[k];
     }
+    if (cfg->space == OXHIP_SPACE_SE2) { dp.lo[2] = th_lo; dp.hi[2] = th_hi; dp.scale[2] = th_hi - th_lo; }
+    dp.space = cfg->space;
     dp.max_distance = cfg->max_distance;
     dp.res = res;
     dp.p_int = bernoulli_p_int(cfg->goal_bias);
@@ -223,6 +247,21 @@ int32_t oxhip_rrt_batch_set_boxes(oxhip_rrt_batch* b, const double* lo, const do
     return OXHIP_OK;
 }
 
+int32_t oxhip_rrt_batch_set_segments(oxhip_rrt_batch* b, const double* segments, uint32_t n, double clearance) {
+    if (!b || (n && !segments)) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (b->cfg.space != OXHIP_SPACE_SE2) return fail(OXHIP_ERR_BAD_ARG, "segments describe the SE(2) checker");
+    if (std::isnan(clearance)) return fail(OXHIP_ERR_BAD_ARG, "clearance is NaN");
+    int32_t st = select_device(b->cfg.device);
+    if (st != OXHIP_OK) return st;
+    std::vector<double> v(segments, segments + (size_t)4 * n);
+    for (double x : v) if (!(std::fabs(x) <= kMaxMagnitude)) return fail(OXHIP_ERR_BAD_ARG, "segment endpoint not finite / too large");
+    if ((st = upload(b->segs, v, b->stream)) != OXHIP_OK) return st;
+    b->dp.segs = b->segs.p;
+    b->dp.n_segs = n;
+    b->dp.seg_thr = sqrt_le_threshold(clearance);
+    return OXHIP_OK;
+}
+
 int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const double* goal_centres,
                               const double* goal_radii) {
     if (!b || !starts || !goal_centres || !goal_radii) return fail(OXHIP_ERR_BAD_ARG, "null argument");
@@ -235,7 +274,8 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
     b->starts.assign(starts, starts + (size_t)P * dim);
     b->filt_dirty = true;
     std::vector<double> thr(P);
-    for (uint32_t p = 0; p < P; ++p) thr[p] = sqrt_le_threshold(goal_radii[p]);
+    // R^n: satisfied iff d2 <= T(radius); SE(2): the compound distance is compared with the radius itself
+    for (uint32_t p = 0; p < P; ++p) thr[p] = b->cfg.space == OXHIP_SPACE_SE2 ? goal_radii[p] : sqrt_le_threshold(goal_radii[p]);
     std::vector<ProblemState> states(P);
     for (auto& s : states) {
         s = ProblemState{};
@@ -383,7 +423,8 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         b->dp.budget = step;
         b->dp.freeze = freeze ? 1 : 0;
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
-        if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
+        if (b->cfg.space == OXHIP_SPACE_SE2) launch_rrt_connect_se2(b->dp, b->stream);
+        else if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) launch_rrt_star(b->dp, b->stream);
         else if (b->kernel_kind == OXHIP_KERNEL_PRUNED) launch_rrt_pruned(b->dp, b->stream);
         else if (b->kernel_kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
@@ -691,7 +732,8 @@ int32_t oxhip_rrt_batch_is_valid(oxhip_rrt_batch* b, const double* states, uint3
     DevBuf<uint8_t> dout;
     OX_TRY(to_device(ds, states, (size_t)n * b->cfg.dim, b->stream));
     HIP_TRY(dout.alloc(n));
-    launch_is_valid(b->dp, ds.p, n, dout.p, b->stream);
+    if (b->cfg.space == OXHIP_SPACE_SE2) launch_se2_is_valid(b->dp, ds.p, n, dout.p, b->stream);
+    else launch_is_valid(b->dp, ds.p, n, dout.p, b->stream);
     HIP_TRY(hipGetLastError());
     return to_host(out, dout, n, b->stream);
 }
@@ -705,7 +747,8 @@ int32_t oxhip_rrt_batch_check_motion(oxhip_rrt_batch* b, const double* from, con
     OX_TRY(to_device(da, from, (size_t)n * b->cfg.dim, b->stream));
     OX_TRY(to_device(db, to, (size_t)n * b->cfg.dim, b->stream));
     HIP_TRY(dout.alloc(n));
-    launch_check_motion(b->dp, da.p, db.p, n, dout.p, b->stream);
+    if (b->cfg.space == OXHIP_SPACE_SE2) launch_se2_check_motion(b->dp, da.p, db.p, n, dout.p, b->stream);
+    else launch_check_motion(b->dp, da.p, db.p, n, dout.p, b->stream);
     HIP_TRY(hipGetLastError());
     return to_host(out, dout, n, b->stream);
 }
@@ -727,6 +770,23 @@ int32_t oxhip_f64_op_batch(int32_t device, uint32_t op, const double* a, const d
     launch_f64_op(op, da.p, db.p, dc.p, n, dout.p, ts.s);
     HIP_TRY(hipGetLastError());
     return to_host(out, dout, n, ts.s);
+}
+
+int32_t oxhip_se2_op_batch(int32_t device, uint32_t op, const double* a, const double* b, const double* t, uint32_t n,
+                           double* out) {
+    if (!a || !b || !out || op > 1 || (op == 1 && !t)) return fail(OXHIP_ERR_BAD_ARG, "bad argument");
+    if (n == 0) return OXHIP_OK;
+    OX_TRY(select_device(device));
+    TmpStream ts;
+    HIP_TRY(hipStreamCreate(&ts.s));
+    DevBuf<double> da, db, dt, dout;
+    OX_TRY(to_device(da, a, (size_t)3 * n, ts.s));
+    OX_TRY(to_device(db, b, (size_t)3 * n, ts.s));
+    if (t) OX_TRY(to_device(dt, t, n, ts.s));
+    HIP_TRY(dout.alloc((size_t)3 * n));
+    launch_se2_op(op, da.p, db.p, dt.p, n, dout.p, ts.s);
+    HIP_TRY(hipGetLastError());
+    return to_host(out, dout, (size_t)3 * n, ts.s);
 }
 
 int32_t oxhip_rng_u64_batch(int32_t device, uint64_t seed, uint64_t stream, uint32_t n, uint64_t* out) {

@@ -63,6 +63,10 @@ struct DevParams {
     double t_steer;         // largest d2 with sqrt(d2) <= max_distance: steer iff d2 > t_steer (exact)
     const double* sph_filt; // [n_spheres] conservative filter: d2(centre, segment midpoint) > filt => sphere cannot be hit
     uint64_t* dbg;          // optional [16] cycle stamps of workgroup 0 (diagnostic build of the resident kernel)
+    // SE(2) only (rrt_connect_se2.hip): segment-soup checker
+    const double* segs;     // [n_segs][4] (ax, ay, bx, by)
+    uint32_t n_segs, space; // space: oxhip_space_kind
+    double seg_thr;         // valid iff d2(point, segment) > seg_thr  (== distance > clearance, exactly)
     // RRT* only (rrt_star.hip)
     double* cost;           // [P][cap] cost-to-come of every node (Node::cost, rrt_star.rs:26)
     uint32_t* nb_idx;       // [P][cap] scratch: find_neighbours' result of the current iteration
