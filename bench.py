@@ -65,7 +65,12 @@ def cpu_baseline(sc, seed, threads, iters):
     t0 = time.perf_counter()
     orc.solve_many(planners, iters, freeze=True, threads=threads)
     dt = time.perf_counter() - t0
+    # the reference is single-threaded per planner: one problem on one core
+    t1 = time.perf_counter()
+    orc.solve_many(planners[:1], iters, freeze=True, threads=1)
+    dt1 = time.perf_counter() - t1
     return planners, dict(value=threads * iters / dt, unit="iterations/s", cores=threads, kind="port",
+                          value_1core=iters / dt1,
                           sample="%d problems x %d frozen iterations at n=10000 on %d threads "
                                  "(oracle/rrt_oracle.c, C restatement of rrt.rs:170-225)" % (threads, iters, threads))
 
@@ -76,6 +81,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--problems", type=int, default=1024, help="problems per GPU")
+    ap.add_argument("--strong-total", type=int, default=0,
+                    help="strong scaling: this many problems in total, divided over the ranks (SURVEY.md 8(d): 8192)")
     ap.add_argument("--iters", type=int, default=4096, help="RRT iterations per problem per step")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident, 3 resident + pruned scan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,6 +112,10 @@ def main():
     from oxmpl_amd import capi, scenarios, sharding
 
     sc = scenarios.config2()
+    if args.strong_total:
+        if args.strong_total % world:
+            raise SystemExit("--strong-total must be a multiple of the rank count")
+        args.problems = args.strong_total // world
     P, seed = args.problems, 42
     first_id, _ = sharding.problem_range(rank, P)
     gpu = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id,
@@ -169,7 +180,8 @@ def main():
         out = {
             "metric": "RRT iterations/sec (batched problems), R^3 10k-node tree, 64-sphere field",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.strong_total else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[1]: R^3 RRT, 64 random spheres, %d problem instances per MI355X, "
                                    "steady@10k (trees pre-grown to 10000 nodes, inserts suppressed)" % P,
@@ -191,7 +203,7 @@ def main():
             out["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:  # the contract: rank 0, N = 1 only
             threads = min(os.cpu_count() or 1, 16)
-            planners, base = cpu_baseline(sc, seed, threads, 6000)
+            planners, base = cpu_baseline(sc, seed, threads, 60000)   # ~25 s of CPU work on 16 threads
             out["cpu_baseline"] = base
         print(json.dumps(out))
     if world > 1:
