@@ -20,15 +20,23 @@ constexpr int kSe2Threads = 256;
 constexpr int kSe2Waves = kSe2Threads / 64;
 #define OXHIP_PI 3.14159265358979323846   // std::f64::consts::PI = 0x400921FB54442D18
 
-// f64::rem_euclid: r = self % rhs; if r < 0.0 { r + rhs.abs() } else { r }   (fmod is exact)
-__device__ __forceinline__ double rem_euclid(double a, double b) {
-    const double r = fmod(a, b);
-    return r < 0.0 ? r + fabs(b) : r;
+// f64::rem_euclid(a, 2*PI): r = a % (2*PI); if r < 0.0 { r + 2*PI } else { r }.  fmod is exact, and for
+// -2*PI < a < 4*PI it needs no division: a in [2*PI, 4*PI) gives a - 2*PI (exact by Sterbenz' lemma, which is
+// fmod's value), a in [0, 2*PI) gives a, a in (-2*PI, 0) gives a, to which the reference then adds 2*PI -- the
+// same rounded addition.  Everything a planner run produces lies in that window; the rest takes fmod.
+__device__ __forceinline__ double rem_euclid_2pi(double a) {
+    const double b = 2.0 * OXHIP_PI;
+    double r;
+    if (a >= 0.0 && a < b) r = a;
+    else if (a >= b && a < 2.0 * b) r = a - b;
+    else if (a < 0.0 && a > -b) r = a;
+    else r = fmod(a, b);
+    return r < 0.0 ? r + b : r;
 }
-__device__ __forceinline__ double so2_normalise(double v) { return rem_euclid(v + OXHIP_PI, 2.0 * OXHIP_PI) - OXHIP_PI; }
+__device__ __forceinline__ double so2_normalise(double v) { return rem_euclid_2pi(v + OXHIP_PI) - OXHIP_PI; }
 __device__ __forceinline__ double so2_distance(double a, double b) {
     double diff = a - b;
-    diff = rem_euclid(diff + OXHIP_PI, 2.0 * OXHIP_PI) - OXHIP_PI;
+    diff = rem_euclid_2pi(diff + OXHIP_PI) - OXHIP_PI;
     return fabs(diff);
 }
 __device__ __forceinline__ double so2_interpolate(double from, double to, double t) {
