@@ -209,6 +209,7 @@ int32_t oxhip_rrt_batch_destroy(oxhip_rrt_batch* b) {
 
 int32_t oxhip_rrt_batch_set_spheres(oxhip_rrt_batch* b, const double* centres, const double* radii, uint32_t n) {
     if (!b || (n && (!centres || !radii))) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (b->cfg.space == OXHIP_SPACE_SE2) return fail(OXHIP_ERR_BAD_ARG, "SE(2) batches take oxhip_rrt_batch_set_segments");
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
     const uint32_t dim = b->cfg.dim;
@@ -232,6 +233,7 @@ int32_t oxhip_rrt_batch_set_spheres(oxhip_rrt_batch* b, const double* centres, c
 
 int32_t oxhip_rrt_batch_set_boxes(oxhip_rrt_batch* b, const double* lo, const double* hi, uint32_t n) {
     if (!b || (n && (!lo || !hi))) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    if (b->cfg.space == OXHIP_SPACE_SE2) return fail(OXHIP_ERR_BAD_ARG, "SE(2) batches take oxhip_rrt_batch_set_segments");
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
     const uint32_t dim = b->cfg.dim;
