@@ -55,3 +55,30 @@ def test_resident_scan_arithmetic_is_unfused(resident_asm):
     assert n_mul > 200 and n_add > 300          # the unrolled sub/mul/add scan
     assert n_fma < n_mul // 4                   # FMAs appear only inside the sqrt / division expansions
     assert "v_med3_u32" in body and "row_bcast:31" in body and "s_setprio" in body
+
+
+@pytest.fixture(scope="module")
+def prm_asm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("asm") / "prm_kernels.s")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "prm_kernels.hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_prm_pair_search_streams_the_i_side_through_scalar_loads(prm_asm):
+    """the design of DESIGN.md section 9: milestones i are wave-uniform scalar operands (s_load), the loop touches
+    neither LDS nor vector memory, nothing spills, and the distance arithmetic is unfused"""
+    meta = {k: v for k, v in _kernels(prm_asm).items() if "prm_pairs_kernel" in k}
+    assert len(meta) == 8                      # dim 1..8
+    for name, m in meta.items():
+        assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, name
+        assert m["max_flat_workgroup_size"] == 256
+    body = prm_asm.split("prm_pairs_kernelILi6EEEvNS_7PrmArgsEPKdjjd:")[1].split("s_endpgm")[0]
+    assert body.count("s_load_dwordx8") >= 2 and body.count("s_load_dwordx4") >= 2   # two register sets in flight
+    assert "v_fma_f64" not in body
+    n_mul, n_add = body.count("v_mul_f64"), body.count("v_add_f64")
+    assert n_mul >= 24 and n_add >= 44         # 2 milestones x 6 dims, two loop bodies (plain + diagonal blocks)
+    # the i side never goes through LDS: the only LDS traffic is the staging buffer of the (rare) hits
+    loop = body.split("sched_barrier")[1]
+    assert "ds_read" not in loop.split("s_cbranch")[0]
