@@ -83,6 +83,8 @@ def test_so2_se2_arithmetic_on_the_device(se2_golden):
         assert bits(out0[i, 1:2])[0] == bits(np.array([L.orc_so2_normalise(a[i, 2])]))[0]
         assert bits(out0[i, 2:3])[0] == bits(np.array([L.orc_so2_distance(a[i, 2], b[i, 2])]))[0]
         assert np.array_equal(bits(out1[i]), bits(orc.se2_interpolate(a[i], b[i], float(t[i]))))
+    # the reference's own exact unit-test vector (so2_state.rs:80-87): normalise(3 PI / 2) == -PI / 2
+    assert capi.se2_op_batch(0, [[0.0, 0.0, 3.0 * math.pi / 2.0]], [[0.0, 0.0, 0.0]])[0, 1] == -math.pi / 2.0
     for k in se2_golden["kat"]["random"]:
         x, y = [unhex(v) for v in k["a"]], [unhex(v) for v in k["b"]]
         o0 = capi.se2_op_batch(0, [x], [y])[0]

@@ -41,9 +41,12 @@ def test_so2_se2_and_segment_kats(se2_golden):
     assert hexf(orc.point_segment_distance(1.0, 2.0, [3.0, 4.0, 3.0, 4.0])) == se2_golden["kat"]["degenerate_segment"]
     b, pb = orc._d([0.0, 10.0, 0.0, 10.0])
     assert hexf(L.orc_se2_extent(pb)) == se2_golden["kat"]["extent"]
-    # the doc examples of so2_state.rs:23-29
+    # the doc examples of so2_state.rs:23-32,49-53
     assert abs(L.orc_so2_normalise(3.0 * math.pi / 2.0) + math.pi / 2.0) < 1e-9
     assert abs(L.orc_so2_normalise(5.0 * math.pi) + math.pi) < 1e-9
+    # the one exact known answer the reference's own unit tests hold for this arithmetic
+    # (so2_state.rs:80-87, test_so2_state_normalise: assert_eq!(state2.value, -PI / 2.0))
+    assert L.orc_so2_normalise(3.0 * math.pi / 2.0) == -math.pi / 2.0
 
 
 def make_oracle(P, seed, pid):
