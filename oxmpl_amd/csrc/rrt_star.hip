@@ -128,7 +128,15 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p) {
         if (!ok) { st.checksum = h; continue; }
         st.accepted++;
 
-        // find_neighbours (rrt_star.rs:121-131): distance(q_new, tree[i]) < search_radius  <=>  d2 <= thr_search
+        // 6a. cost via the nearest node: cost(temp_node, q_near_node) = q_near.cost + distance(q_new, q_near) (:104-113, :228)
+        uint32_t best_parent = nearest;
+        double min_cost = cost[nearest] + sqrt(dist2<D>(q_new, q_near, dim));
+        const double init_cost = min_cost;
+
+        // find_neighbours (rrt_star.rs:121-131): distance(q_new, tree[i]) < search_radius  <=>  d2 <= thr_search.
+        // The same pass already finds the first choose-parent candidate: the lexicographic minimum of
+        // (cost via neighbour, index) among the neighbours cheaper than the nearest node.
+        Exact m{__builtin_inf(), 0xFFFFFFFFu};
         for (uint32_t i = tid; i < n; i += kStarThreads) {
             double c[D];
 #pragma unroll
@@ -136,47 +144,48 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p) {
             const double d2 = dist2<D>(q_new, c, dim);
             if (d2 <= p.thr_search) {
                 const uint32_t slot = atomicAdd(&sh.nb_count, 1u);
+                const double d = sqrt(d2);
                 nb_idx[slot] = i;
-                nb_dist[slot] = sqrt(d2);
+                nb_dist[slot] = d;
+                const double cv = cost[i] + d;
+                if (cv < init_cost && (cv < m.dist || (cv == m.dist && i < m.idx))) { m.dist = cv; m.idx = i; }
             }
         }
+        m = exact_wave_reduce(m);
+        if (lane == 0) sh.wave_exact[wave] = m;
         __syncthreads();
         const uint32_t nbc = sh.nb_count;
+        m = sh.wave_exact[0];
+#pragma unroll
+        for (int w = 1; w < kStarWaves; ++w) m = exact_combine(m, sh.wave_exact[w]);
 
-        // 6. choose parent (rrt_star.rs:225-241)
-        uint32_t best_parent = nearest;
-        double min_cost = cost[nearest] + sqrt(dist2<D>(q_new, q_near, dim));   // cost(temp_node, q_near_node), :104-113
-        {
-            const double init_cost = min_cost;
-            double last_c = -__builtin_inf();
-            uint32_t last_i = 0;
-            for (;;) {
-                Exact m{__builtin_inf(), 0xFFFFFFFFu};   // (cost via neighbour, neighbour index), lexicographic minimum
-                for (uint32_t e = tid; e < nbc; e += kStarThreads) {
-                    const uint32_t idx = nb_idx[e];
-                    const double c = cost[idx] + nb_dist[e];
-                    const bool after = c > last_c || (c == last_c && idx > last_i);   // not yet tried
-                    if (c < init_cost && after && (c < m.dist || (c == m.dist && idx < m.idx))) { m.dist = c; m.idx = idx; }
-                }
-                m = exact_wave_reduce(m);
-                if (lane == 0) sh.wave_exact[wave] = m;
-                __syncthreads();
-                m = sh.wave_exact[0];
+        // 6b. choose parent (rrt_star.rs:225-241): candidates in increasing (cost, index) order until a motion is valid
+        while (m.idx != 0xFFFFFFFFu) {
+            double from[D];
 #pragma unroll
-                for (int w = 1; w < kStarWaves; ++w) m = exact_combine(m, sh.wave_exact[w]);
-                if (m.idx == 0xFFFFFFFFu) break;         // nobody cheaper than the nearest node is left
-                double from[D];
-#pragma unroll
-                for (int k = 0; k < D; ++k) if (k < dim) from[k] = tree[(size_t)k * cap + m.idx];
-                const bool bad2 = motion_invalid_partial<D>(p, dim, from, q_new, tid, kStarThreads);
-                if (!__syncthreads_or(bad2 ? 1 : 0)) {   // check_motion(neighbour, q_new) holds: this is the parent
-                    best_parent = m.idx;
-                    min_cost = m.dist;
-                    break;
-                }
-                last_c = m.dist;
-                last_i = m.idx;
+            for (int k = 0; k < D; ++k) if (k < dim) from[k] = tree[(size_t)k * cap + m.idx];
+            const bool bad2 = motion_invalid_partial<D>(p, dim, from, q_new, tid, kStarThreads);
+            if (!__syncthreads_or(bad2 ? 1 : 0)) {   // check_motion(neighbour, q_new) holds: this is the parent
+                best_parent = m.idx;
+                min_cost = m.dist;
+                break;
             }
+            // rare: that motion is blocked; the next candidate is the smallest (cost, index) above it
+            const double last_c = m.dist;
+            const uint32_t last_i = m.idx;
+            m = Exact{__builtin_inf(), 0xFFFFFFFFu};
+            for (uint32_t e = tid; e < nbc; e += kStarThreads) {
+                const uint32_t idx = nb_idx[e];
+                const double cv = cost[idx] + nb_dist[e];
+                const bool after = cv > last_c || (cv == last_c && idx > last_i);
+                if (cv < init_cost && after && (cv < m.dist || (cv == m.dist && idx < m.idx))) { m.dist = cv; m.idx = idx; }
+            }
+            m = exact_wave_reduce(m);
+            if (lane == 0) sh.wave_exact[wave] = m;
+            __syncthreads();
+            m = sh.wave_exact[0];
+#pragma unroll
+            for (int w = 1; w < kStarWaves; ++w) m = exact_combine(m, sh.wave_exact[w]);
         }
 
         // 7. push (rrt_star.rs:244-250)
