@@ -256,6 +256,19 @@ __device__ __forceinline__ bool motion_invalid_partial(const DevParams& p, int d
     }
     const uint64_t total = (uint64_t)nsteps * nobs;
     const double dn = (double)nsteps;
+    if (total <= 0xFFFFFFFFull) {   // the usual case: 32-bit index arithmetic (a 64-bit divide is ~10x dearer)
+        const uint32_t total32 = (uint32_t)total;
+        for (uint32_t w = tid; w < total32; w += nthreads) {
+            const uint32_t q = w / nobs;
+            const uint32_t j = w - q * nobs;
+            const double t = (double)(q + 1) / dn;
+            double s[D];
+            lerp<D>(from, to, t, s, dim);
+            bad = bad || obstacle_hit<D>(p, dim, s, j);
+            if (w + nthreads < w) break;   // index wrap (total32 near 2^32)
+        }
+        return bad;
+    }
     for (uint64_t w = tid; w < total; w += nthreads) {
         uint32_t step = (uint32_t)(w / nobs) + 1;
         uint32_t j = (uint32_t)(w % nobs);
@@ -263,6 +276,103 @@ __device__ __forceinline__ bool motion_invalid_partial(const DevParams& p, int d
         double s[D];
         lerp<D>(from, to, t, s, dim);
         bad = bad || obstacle_hit<D>(p, dim, s, j);
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------- obstacle table in LDS
+// The sphere / box table is read by every motion check; small tables (the usual case: 64 spheres in R^3 = 2 KB)
+// are copied into LDS once per launch and the kernel's private copy of DevParams points there, so obstacle_hit
+// reads them at LDS latency instead of an L2 round trip per (step, obstacle) pair.
+constexpr int kObsLdsDoubles = 1024;
+struct ObsLds { double data[kObsLdsDoubles]; };
+
+// Returns the parameters to use from now on; the caller issues a workgroup barrier before the first motion check.
+__device__ __forceinline__ DevParams stage_obstacles(const DevParams& p, ObsLds& buf, uint32_t tid, uint32_t nthreads) {
+    const uint32_t ns = p.n_spheres, nb = p.n_boxes, dim = p.dim;
+    const uint32_t need = (dim + 1) * ns + 2 * dim * nb;
+    if (need == 0 || need > (uint32_t)kObsLdsDoubles) return p;
+    double* c = buf.data;                 // [dim][ns]
+    double* thr = c + dim * ns;           // [ns]
+    double* lo = thr + ns;                // [dim][nb]
+    double* hi = lo + dim * nb;           // [dim][nb]
+    for (uint32_t i = tid; i < dim * ns; i += nthreads) c[i] = p.sph_c[i];
+    for (uint32_t i = tid; i < ns; i += nthreads) thr[i] = p.sph_thr[i];
+    for (uint32_t i = tid; i < dim * nb; i += nthreads) { lo[i] = p.box_lo[i]; hi[i] = p.box_hi[i]; }
+    DevParams q = p;
+    q.sph_c = c; q.sph_thr = thr; q.box_lo = lo; q.box_hi = hi;
+    return q;
+}
+
+// ---------------------------------------------------------------- wave-wide minima on the DPP crossbar
+// Six data-parallel-primitive steps (quad perms, row mirrors, row broadcasts) instead of six ds_bpermute
+// round trips: ~20 VALU instructions, no LDS traffic.  A shuffle-based (__shfl_xor) reduction of a
+// (double, double, index) triple costs ~3,000 cycles per call on this chip -- measured: it was 45 % of an
+// RRTConnect iteration -- because every step is a dependent LDS-crossbar access.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_min_step(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    // bound_ctrl = false + old = own value: lanes without a source keep their own value
+    int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    // plain v_min_f64: the operands are squared distances (never NaN), so the canonicalising
+    // v_max_f64 x,x that fmin() would add in front of every step is dead weight
+    double o = __hiloint2double(ohi, olo), r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
+    return r;
+}
+
+__device__ __forceinline__ double wave_min_f64(double v) {
+    v = dpp_min_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_min_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_min_step<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_min_step<0x140, 0xf>(v);  // row_mirror          -> every lane holds its row's min
+    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave min
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_umin_step(uint32_t v) {
+    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = dpp_umin_step<0xB1, 0xf>(v);
+    v = dpp_umin_step<0x4E, 0xf>(v);
+    v = dpp_umin_step<0x141, 0xf>(v);
+    v = dpp_umin_step<0x140, 0xf>(v);
+    v = dpp_umin_step<0x142, 0xa>(v);
+    v = dpp_umin_step<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// rrt.rs:90-116 for a 256-thread workgroup.  With many obstacles the steps are dealt to the waves and the
+// obstacles to the lanes: the interpolation parameter and the interpolated state are computed once per step and
+// are wave-uniform, no index division is needed, and a lane keeps meeting the same obstacles.  With few obstacles
+// and many steps that would idle most lanes, so the (step, obstacle) pairs are striped over all threads instead.
+template <int D>
+__device__ __forceinline__ bool motion_invalid_wg(const DevParams& p, int dim, const double from[D], const double to[D],
+                                                  uint32_t tid, uint32_t nthreads) {
+    const uint32_t nobs = p.n_spheres + p.n_boxes;
+    if (nobs < 32) return motion_invalid_partial<D>(p, dim, from, to, tid, nthreads);
+    const double dist = sqrt(dist2<D>(from, to, dim));
+    const uint32_t nsteps = num_steps_u32(dist, p.res);
+    const uint32_t wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
+    bool bad = false;
+    if (nsteps <= 1) {
+        for (uint32_t j = tid; j < nobs; j += nthreads) bad = bad || obstacle_hit<D>(p, dim, to, j);
+        return bad;
+    }
+    const double dn = (double)nsteps;
+    for (uint32_t step = wave + 1; step <= nsteps && step > wave; step += nwaves) {   // `step > wave`: no wrap at 2^32
+        const double t = (double)step / dn;
+        double s[D];
+        lerp<D>(from, to, t, s, dim);
+        for (uint32_t j = lane; j < nobs; j += 64) bad = bad || obstacle_hit<D>(p, dim, s, j);
     }
     return bad;
 }
@@ -297,16 +407,18 @@ __device__ __forceinline__ Best best_combine(const Best& a, const Best& b) {
     return r;
 }
 
+// Wave-wide combine of the per-lane (b1, b2, i1): b1 = min; i1 = lowest index attaining it; b2 = second
+// smallest d2 with multiplicity (= b1 when two lanes attain it; else the smaller of the other lanes' minima
+// and the winning lane's own second).  Every lane returns the same value.
 __device__ __forceinline__ Best best_wave_reduce(Best v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Best o;
-        o.b1 = __shfl_xor(v.b1, off, 64);
-        o.b2 = __shfl_xor(v.b2, off, 64);
-        o.i1 = __shfl_xor(v.i1, off, 64);
-        v = best_combine(v, o);
-    }
-    return v;
+    const double m = wave_min_f64(v.b1);
+    const bool win = v.b1 == m;
+    Best r;
+    r.b1 = m;
+    r.i1 = wave_min_u32(win ? v.i1 : 0xFFFFFFFFu);
+    const double second = wave_min_f64(win ? v.b2 : v.b1);
+    r.b2 = __popcll(__ballot(win)) >= 2 ? m : second;
+    return r;
 }
 
 // near-tie test: could another node's sqrt(d2) equal sqrt(b1)?
@@ -324,15 +436,12 @@ __device__ __forceinline__ Exact exact_combine(const Exact& a, const Exact& b) {
     bool bw = (b.dist < a.dist) || (b.dist == a.dist && b.idx < a.idx);
     return bw ? b : a;
 }
+// lexicographic (dist, idx) minimum over the wave; every lane returns it
 __device__ __forceinline__ Exact exact_wave_reduce(Exact v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        Exact o;
-        o.dist = __shfl_xor(v.dist, off, 64);
-        o.idx = __shfl_xor(v.idx, off, 64);
-        v = exact_combine(v, o);
-    }
-    return v;
+    Exact r;
+    r.dist = wave_min_f64(v.dist);
+    r.idx = wave_min_u32(v.dist == r.dist ? v.idx : 0xFFFFFFFFu);
+    return r;
 }
 
 __device__ __forceinline__ uint64_t fnv_mix(uint64_t h, uint64_t v) { return (h ^ v) * kFnvPrime; }

@@ -9,31 +9,6 @@ namespace oxhip {
 
 
 // ---- wave64 min of an f64 with DPP (VALU only, no LDS crossbar); result is wave-uniform
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_min_step(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    // bound_ctrl = false + old = own value: lanes without a source keep their own value
-    int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    // plain v_min_f64: the operands are squared distances (never NaN), so the canonicalising
-    // v_max_f64 x,x that fmin() would add in front of every step is dead weight
-    double o = __hiloint2double(ohi, olo), r;
-    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(o));
-    return r;
-}
-
-__device__ __forceinline__ double wave_min_f64(double v) {
-    v = dpp_min_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
-    v = dpp_min_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
-    v = dpp_min_step<0x141, 0xf>(v);  // row_half_mirror
-    v = dpp_min_step<0x140, 0xf>(v);  // row_mirror          -> every lane holds its row's min
-    v = dpp_min_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
-    v = dpp_min_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave min
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -189,20 +164,6 @@ __device__ __forceinline__ void lds_bump(uint32_t* p) {
     __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_umin_step(uint32_t v) {
-    uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
-    return o < v ? o : v;
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-    v = dpp_umin_step<0xB1, 0xf>(v);
-    v = dpp_umin_step<0x4E, 0xf>(v);
-    v = dpp_umin_step<0x141, 0xf>(v);
-    v = dpp_umin_step<0x140, 0xf>(v);
-    v = dpp_umin_step<0x142, 0xa>(v);
-    v = dpp_umin_step<0x143, 0xc>(v);
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
 
 // steer (rrt.rs:199-208): q_new = q when within max_distance of q_near, else the point at max_distance.
 // `have_dist`: g_or_dist is the post-sqrt distance (exact path); otherwise it is d2 and the test
