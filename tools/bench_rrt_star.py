@@ -51,8 +51,13 @@ for p in (0, CPU_P - 1):
     gs, _ = g.tree(p)
     os_, _ = planners[p].tree()
     same = same and bool(np.array_equal(gs[:CPU_N].view(np.uint64), os_.view(np.uint64)))
-# algorithmic bytes: two scans of the tree per accepted iteration (nearest, find_neighbours), one per rejected
-print(json.dumps({"planner": "RRTStar", "workload": "R^3, 64 spheres, %d problems, 1 -> %d nodes, search radius %g" % (P, N, R),
+# algorithmic bytes: two scans of the tree per accepted iteration (nearest + find_neighbours: 2 * 24 * n at n nodes),
+# one per rejected iteration (rejections are spread over the growth: charged at the mean tree size)
+acc = P * (N - 1)
+alg_bytes = 2 * 24 * P * (N - 1) * N / 2 + (its - acc) * 24 * N / 2
+print(json.dumps({"roofline": {"bound": "hbm", "achieved": alg_bytes / (k * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": alg_bytes / (k * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": alg_bytes},
+                  "planner": "RRTStar", "workload": "R^3, 64 spheres, %d problems, 1 -> %d nodes, search radius %g" % (P, N, R),
                   "kernel_ms": k, "iterations": its, "iterations_per_s": its / (k * 1e-3),
                   "nodes_per_s": P * (N - 1) / (k * 1e-3), "mean_goal_cost_sample": goal_cost,
                   "cpu_oracle": {"kind": "port", "problems": CPU_P, "max_nodes": CPU_N, "threads": 16,
