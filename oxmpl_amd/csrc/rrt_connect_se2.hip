@@ -84,35 +84,35 @@ __device__ __forceinline__ bool segment_hit(const DevParams& p, const double s[3
     return !(point_segment_d2(p, s[0], s[1], j) > p.seg_thr);
 }
 
-// rrt_connect.rs:166-189: (step, segment) pairs striped over `nthreads` callers; returns this caller's flag
+// rrt_connect.rs:166-189 for `nthreads` callers (a multiple of 64); returns this caller's flag.  The steps are
+// dealt to the waves and the segments to the lanes: the interpolated state (one normalisation chain) is computed
+// once per step and is wave-uniform, no index division is needed.
 __device__ __forceinline__ bool se2_motion_invalid_partial(const DevParams& p, const double from[3], const double to[3],
                                                            uint32_t tid, uint32_t nthreads) {
     if (p.n_segs == 0) return false;
     const double dist = se2_distance(from, to);
     const uint32_t nsteps = num_steps_u32(dist, p.res);
+    const uint32_t wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
     bool bad = false;
     if (nsteps <= 1) {
         for (uint32_t j = tid; j < p.n_segs; j += nthreads) bad = bad || segment_hit(p, to, j);
         return bad;
     }
-    const uint64_t total = (uint64_t)nsteps * p.n_segs;
     const double dn = (double)nsteps;
-    uint32_t cur_step = 0;
-    double s[3] = {0.0, 0.0, 0.0};
-    for (uint64_t w = tid; w < total; w += nthreads) {
-        const uint32_t step = (uint32_t)(w / p.n_segs) + 1, j = (uint32_t)(w % p.n_segs);
-        if (step != cur_step) {   // the interpolation (one fmod chain) is shared by the segments of a step
-            se2_interpolate(from, to, (double)step / dn, s);
-            cur_step = step;
-        }
-        bad = bad || segment_hit(p, s, j);
+    for (uint32_t step = wave + 1; step <= nsteps && step > wave; step += nwaves) {   // `step > wave`: no wrap at 2^32
+        double s[3];
+        se2_interpolate(from, to, (double)step / dn, s);
+        for (uint32_t j = lane; j < p.n_segs; j += 64) bad = bad || segment_hit(p, s, j);
     }
     return bad;
 }
 
+constexpr int kSe2LdsSegs = 512;   // segments staged in LDS (16 KB); larger soups are read from HBM / L2
+
 struct Se2Shared {
     uint32_t rng_buf[16][64];
     Exact wave_exact[kSe2Waves];
+    double segs[kSe2LdsSegs][4];
 };
 
 // extend() of rrt_connect.rs:121-159; 0 = motion invalid, 1 = Advanced, 2 = Reached
@@ -156,6 +156,10 @@ __device__ __forceinline__ int se2_extend(const DevParams& p, Se2Shared& sh, dou
 __global__ __launch_bounds__(kSe2Threads) void rrt_connect_se2_kernel(DevParams p) {
     const uint32_t prob = blockIdx.x, tid = threadIdx.x;
     __shared__ Se2Shared sh;
+    if (p.n_segs <= (uint32_t)kSe2LdsSegs) {   // the checker's table at LDS latency (made visible by the first barrier)
+        for (uint32_t i = tid; i < 4 * p.n_segs; i += kSe2Threads) (&sh.segs[0][0])[i] = p.segs[i];
+        p.segs = &sh.segs[0][0];
+    }
     ProblemState st = p.state[prob];
     if (st.goal_node >= 0) return;
     const size_t cap = p.cap;
