@@ -31,11 +31,13 @@ struct StarShared {
 };
 
 template <int DIM>
-__global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p) {
+__global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p_in) {
     constexpr int D = DIM ? DIM : kMaxDim;
-    const int dim = DIM ? DIM : (int)p.dim;
+    const int dim = DIM ? DIM : (int)p_in.dim;
     const uint32_t prob = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     __shared__ StarShared sh;
+    __shared__ ObsLds obs;
+    const DevParams p = stage_obstacles(p_in, obs, tid, kStarThreads);   // visible after the first barrier of iteration 0
 
     ProblemState st = p.state[prob];
     if (p.stop_at_goal && st.goal_node >= 0) return;
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p) {
         }
 
         // 5. check_motion(q_near, q_new) (rrt_star.rs:212-214)
-        const bool bad = motion_invalid_partial<D>(p, dim, q_near, q_new, tid, kStarThreads);
+        const bool bad = motion_invalid_wg<D>(p, dim, q_near, q_new, tid, kStarThreads);
         const bool ok = !__syncthreads_or(bad ? 1 : 0);
         uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
 #pragma unroll
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p) {
             double from[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) if (k < dim) from[k] = tree[(size_t)k * cap + m.idx];
-            const bool bad2 = motion_invalid_partial<D>(p, dim, from, q_new, tid, kStarThreads);
+            const bool bad2 = motion_invalid_wg<D>(p, dim, from, q_new, tid, kStarThreads);
             if (!__syncthreads_or(bad2 ? 1 : 0)) {   // check_motion(neighbour, q_new) holds: this is the parent
                 best_parent = m.idx;
                 min_cost = m.dist;

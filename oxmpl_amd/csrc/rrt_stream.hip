@@ -13,9 +13,11 @@ constexpr int kStreamWaves = kStreamThreads / 64;
 
 // D = compile-time array extent; DIM = 0 selects the runtime-dim variant (D = 8)
 template <int DIM>
-__global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p) {
+__global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_in) {
     constexpr int D = DIM ? DIM : kMaxDim;
-    const int dim = DIM ? DIM : (int)p.dim;
+    const int dim = DIM ? DIM : (int)p_in.dim;
+    __shared__ ObsLds obs;
+    const DevParams p = stage_obstacles(p_in, obs, threadIdx.x, kStreamThreads);   // visible after the first barrier
     const uint32_t prob = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = tid >> 6, lane = tid & 63;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p)
         }
 
         // 5. check_motion (rrt.rs:211 -> :90-116), (step, obstacle) pairs over the workgroup
-        bool bad = motion_invalid_partial<D>(p, dim, q_near, q_new, tid, kStreamThreads);
+        bool bad = motion_invalid_wg<D>(p, dim, q_near, q_new, tid, kStreamThreads);
         const bool ok = !__syncthreads_or(bad ? 1 : 0);
 
         uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
