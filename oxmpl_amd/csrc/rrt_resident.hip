@@ -14,6 +14,19 @@
 #include "rrt_resident_common.hpp"
 
 namespace oxhip {
+// Coordinates of node i for the resolver.  The scanners publish only (d2, index): copying the winning slot out of a
+// register array costs every scanner wave a 21-way uniform branch ladder per query (~180 scalar instructions), and
+// seven of eight waves lose anyway (167.7 -> 189.4 M it/s without it).  The resolver fetches the one node it needs:
+// from the LDS ring of the last 64 commits when the node is that young (its HBM store may still be in flight),
+// else from the persistent copy in HBM / L2, which this same wave wrote at least 64 commits -- and several
+// `s_waitcnt vmcnt(0)` -- ago, or which predates the launch.
+template <int DIM>
+__device__ __forceinline__ double node_coord(const PipeShared<DIM>& sh, const double* tree, size_t cap, uint32_t n_start,
+                                             uint32_t n_now, int k, uint32_t i) {
+    if (i >= n_start && i + 64u >= n_now) return sh.newn[i & 63][k];
+    return __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int DIM, int S, bool STAMP>
 __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p) {
     constexpr int D = DIM;
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                 if ((uint32_t)b < nb) {
                     const uint32_t slot = (j + (uint32_t)b) & (kRing - 1);
                     WavePub<DIM>& out = sh.pub[slot][wave];
-                    store_slot<DIM, S>(tr, wslot[b], (int)lane == wl[b], out.c);
+                    // (the candidate's coordinates are not published: see node_coord)
                     if (lane == 0) {
                         out.b1 = wmin[b];
                         out.i1 = Lay::node_index(wave, (uint32_t)wl[b], wslot[b]);
@@ -224,7 +237,8 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         double dist_or_g;
         if (!amb) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) q_near[k] = from_scan ? unid(sh.pub[slot][wl].c[k]) : unid(sh.newn[wl][k]);
+            for (int k = 0; k < D; ++k)
+                q_near[k] = from_scan ? unid(node_coord<DIM>(sh, tree, cap, st0.n_nodes, n, k, nearest)) : unid(sh.newn[wl][k]);
             dist_or_g = g;
             dup = g == 0.0;
         } else {
@@ -345,7 +359,9 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         const bool amb_r = ((uint32_t)(__ballot(amb_l) >> (16 * row)) & 0xFFFFu) != 0 || (rowS == 0 && rowP == 0);
         double q_near[D], qn[D], mid[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) q_near[k] = from_scan ? sh.pub[slot_r][wsub].c[k] : sh.newn[nearest_r & 63][k];
+        for (int k = 0; k < D; ++k)
+            q_near[k] = from_scan ? node_coord<DIM>(sh, tree, cap, st0.n_nodes, n0, k, active && nearest_r != kNoNode ? nearest_r : 0u)
+                                  : sh.newn[nearest_r & 63][k];
         steer<DIM>(p, false, g_r, q_near, q, qn);
         lerp<DIM>(q_near, qn, 0.5, mid, DIM);
         bool maybe_l = false;
