@@ -71,7 +71,16 @@ def case_rv(planner):
     if len(blo):
         g.set_boxes(blo, bhi)
     g.setup(start, goal, gr)
-    g.solve(iters)
+    if rng.random() < 0.4:                      # the same budget in two or three solve calls (resume)
+        a = int(rng.integers(1, iters))
+        g.solve(a)
+        if rng.random() < 0.5 and iters - a > 1:
+            b = int(rng.integers(1, iters - a))
+            g.solve(b)
+            a += b
+        g.solve(iters - a)
+    else:
+        g.solve(iters)
     c = g.counts()
     for p in range(nprob):
         if planner == capi.PLANNER_RRT:
