@@ -86,6 +86,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
             for (uint32_t i = n_local; i < nc; ++i) {
                 uint32_t owner_thread, sl;
                 Lay::locate(i, owner_thread, sl);
+                if ((owner_thread >> 6) != wave) continue;   // another wave's node: skip the slot ladder below
                 const bool mine = tid == owner_thread;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
