@@ -7,11 +7,14 @@
 //    consecutive sorted positions) holds spatial neighbours and carries a tight axis-aligned box.
 //    Nodes committed afterwards are appended behind the sorted ones; once they exceed
 //    max(512, n/8) the resolver drains the ring, the workgroup meets at a barrier and re-sorts.
-//  * Pruned scan: a wave computes the 21 box lower bounds of a query in one lane-parallel step, scans
-//    the row with the smallest bound, then only rows whose bound does not exceed that row's best d2
-//    (times 1 + 2^-30).  A skipped row cannot hold the nearest node nor one tying with it after sqrt
-//    (ties differ by <= 3 ulps), so the (d2, index, near-tie flag) a wave publishes is exactly what
-//    the full scan would publish or flag, and everything downstream is unchanged.
+//  * Pruned scan: lane r of a wave holds the box of the wave's row r.  For a query every lane computes the
+//    smallest (lb) and the largest (ub) squared distance from the query to its box; some node of the wave is
+//    no farther than min_r ub, so only rows with lb <= min_r ub * (1 + 2^-30) can hold the wave's nearest
+//    node or one tying with it after sqrt (ties differ by <= 3 ulps).  Those rows -- typically 2-3 of 21,
+//    because consecutive chunks of the Morton order are dealt to the eight waves in turn, so every wave
+//    covers the whole space sparsely -- are scanned under one static, wave-uniform branch each: no
+//    dynamic register indexing, no dispatch ladder.  The (d2, index, near-tie flag) a wave publishes is
+//    exactly what the full scan would publish, and everything downstream is unchanged.
 //
 // Row order inside a lane is no longer index order, so an exact d2 tie inside one lane is reported
 // as ambiguous (it already is: the second-smallest-high-dword detector fires on equality) and takes
@@ -19,6 +22,10 @@
 #include "oxhip_internal.hpp"
 #include "rrt_device.hpp"
 #include "rrt_resident_common.hpp"
+
+#ifndef OXHIP_PRUNE_PER_QUERY
+#define OXHIP_PRUNE_PER_QUERY 1   // 1: a selected row is scanned only for the queries that selected it; 0: for the whole pass
+#endif
 
 namespace oxhip {
 
@@ -31,6 +38,7 @@ struct SortShared {
     uint32_t hist[kCells];                    // counting sort: histogram, then running offsets
     uint16_t perm[Layout<S>::kCapacity];      // sorted position -> node index (build phase only)
     uint16_t idx_tab[S][kScanThreads];        // (slot, scanner thread) -> node index
+    double box[kScanWaves][2 * 3][64];         // [wave][lo_k / hi_k][row]: the bounding box of every register row
     uint32_t wave_tot[kPipeThreads / 64];
     uint32_t n_sorted;
     uint32_t resort_at;                       // scanners stop before this query and meet the resolver at the barrier
@@ -50,6 +58,19 @@ __device__ __forceinline__ double box_lb2(const double lo[DIM], const double hi[
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
         const double d = vmax_f64(vmax_f64(lo[k] - q[k], 0.0), q[k] - hi[k]);
+        acc = acc + d * d;
+    }
+    return acc;
+}
+
+// largest squared distance from q to the box (farthest corner); an empty box gives +inf
+template <int DIM>
+__device__ __forceinline__ double box_ub2(const double lo[DIM], const double hi[DIM], const double q[DIM]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const double a = q[k] - lo[k], b = hi[k] - q[k];
+        const double d = vmax_f64(fabs(a), fabs(b));
         acc = acc + d * d;
     }
     return acc;
@@ -92,6 +113,14 @@ __device__ __forceinline__ void scan_row(const double (&tr)[DIM][S], uint32_t sl
     }
 }
 
+// the resolver's fetch of a scan winner's coordinates (see node_coord in rrt_resident.hip)
+template <int DIM>
+__device__ __forceinline__ double node_coord_p(const PipeShared<DIM>& sh, const double* tree, size_t cap, uint32_t n_start,
+                                               uint32_t n_now, int k, uint32_t i) {
+    if (i >= n_start && i + 64u >= n_now) return sh.newn[i & 63][k];
+    return __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int DIM, int S, bool STAMP>
 __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
     constexpr int D = DIM;
@@ -131,7 +160,6 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
     if (is_scanner) {
         // ---- scanner state: the tree rows, their boxes (lane r holds the box of row r of this wave), the next query
         double tr[DIM][S];
-        double blo[D], bhi[D];
         uint32_t j = 0, n_local = 0;
         uint32_t n_base = 0, pos_base = 0;  // node i >= n_base sits at sorted position pos_base + (i - n_base)
         uint64_t ts_wait = 0, ts_pre = 0, ts_scan = 0, ts_red = 0, ts_rows = 0, t_mark = 0;
@@ -204,9 +232,9 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
     #pragma unroll
                     for (int k = 0; k < DIM; ++k) tr[k][s] = live ? tree[(size_t)k * cap + idx] : __builtin_inf();
                 }
-                // boxes: lane r keeps the box of row r (+inf / -inf when the row is empty)
+                // boxes in LDS: entry r of this wave = the box of its row r (+inf / -inf when the row is empty)
     #pragma unroll
-                for (int k = 0; k < D; ++k) { blo[k] = __builtin_inf(); bhi[k] = -__builtin_inf(); }
+                for (int k = 0; k < D; ++k) { ss.box[wave][k][lane] = __builtin_inf(); ss.box[wave][D + k][lane] = -__builtin_inf(); }
     #pragma unroll
                 for (int s = 0; s < S; ++s) {
     #pragma unroll
@@ -214,7 +242,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
                         const double v = tr[k][s];
                         const double mn = wave_min_f64(v);
                         const double mx = wave_max_f64(v < __builtin_inf() ? v : -__builtin_inf());
-                        if (lane == (uint32_t)s) { blo[k] = mn; bhi[k] = mx; }
+                        if (lane == 0) { ss.box[wave][k][s] = mn; ss.box[wave][D + k][s] = mx; }
                     }
                 }
             }
@@ -265,54 +293,78 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
                         }
                         if (lane == sl && c[0] < __builtin_inf()) {   // grow the row's box (skipped duplicates are +inf)
 #pragma unroll
-                            for (int k = 0; k < D; ++k) { blo[k] = c[k] < blo[k] ? c[k] : blo[k]; bhi[k] = c[k] > bhi[k] ? c[k] : bhi[k]; }
+                            for (int k = 0; k < D; ++k) {
+                                const double l0 = ss.box[wave][k][sl], h0 = ss.box[wave][D + k][sl];
+                                ss.box[wave][k][sl] = c[k] < l0 ? c[k] : l0;
+                                ss.box[wave][D + k][sl] = c[k] > h0 ? c[k] : h0;
+                            }
                         }
                     }
                 }
                 n_local = nc;
                 if (STAMP) { uint64_t now = (uint64_t)clock64(); ts_pre += now - t_mark; t_mark = now; }
-                // ---- pruned scan, one query of the pass at a time (keeps a single query's state in registers)
-                for (uint32_t b = 0; b < nb; ++b) {
-                    const uint32_t slot = (j + b) & (kRing - 1);
-                    double q[D];
+                // ---- row selection: lane r holds the box of row r; per query one lb, one ub, one wave minimum
+                double q[kBatch][D];
+                uint64_t rows[kBatch];          // wave-uniform: bit r set = row r must be scanned for query b
+                {
+                    double blo[D], bhi[D];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) q[k] = unid(sh.qring[slot].q[k]);
-                    // lane r: lower bound of row r; phase 1 scans the row with the smallest bound
-                    const double lb = box_lb2<D>(blo, bhi, q);
-                    const double lbmin = wave_min_f64(lb);
-                    const uint64_t m0 = __ballot(lb == lbmin);
-                    const int r0 = m0 ? (__ffsll((unsigned long long)m0) - 1) : 0;
-                    Scan sc{__builtin_inf(), 0u, 0xFFFFFFFFu};
-                    if (lbmin < __builtin_inf()) scan_row<DIM, S>(tr, (uint32_t)r0, q, sc);
-                    double wmin = wave_min_f64(sc.b1);
-                    // phase 2: every other row whose bound does not exceed that best (1 + 2^-30 margin)
-                    const double bound = wmin * (1.0 + 9.313225746154785e-10);
-                    uint64_t more = __ballot(lb < __builtin_inf() && lb <= bound) & ~(1ull << r0);
-                    if (more != 0) {
-                        if (STAMP) ts_rows += (uint64_t)__popcll(more);
-                        while (more != 0) {
-                            const int s = __ffsll((unsigned long long)more) - 1;
-                            scan_row<DIM, S>(tr, (uint32_t)s, q, sc);
-                            more &= more - 1;
-                        }
-                        wmin = wave_min_f64(sc.b1);
+                    for (int k = 0; k < D; ++k) { blo[k] = ss.box[wave][k][lane]; bhi[k] = ss.box[wave][D + k][lane]; }
+#pragma unroll
+                    for (int b = 0; b < kBatch; ++b) {
+                        const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kRing - 1);
+#pragma unroll
+                        for (int k = 0; k < D; ++k) q[b][k] = unid(sh.qring[slot].q[k]);
+                        const double lb = box_lb2<D>(blo, bhi, q[b]);
+                        const double ub = box_ub2<D>(blo, bhi, q[b]);          // +inf for an empty row
+                        const double um = wave_min_f64(ub);
+                        const double bound = __builtin_fma(um, 0x1p-30, um);   // * (1 + 2^-30); 2^-30 is an inline literal
+                        rows[b] = (uint32_t)b < nb ? __ballot(lb <= bound) : 0ull;   // empty rows: lb = +inf, never selected
                     }
-                    const uint64_t eqm = __ballot(sc.b1 == wmin);
-                    const int wl = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
-                    const uint32_t wslot = __builtin_amdgcn_readlane(sc.slot, wl);
-                    const uint32_t hb = hi32(wmin) + 1;
-                    const bool amb_l = ((int)lane != wl && hi32(sc.b1) <= hb) || (sc.h2 <= hb);
-                    const uint32_t wamb = __ballot(amb_l) != 0 ? 1u : 0u;
-                    WavePub<DIM>& out = sh.pub[slot][wave];
-                    store_slot<DIM, S>(tr, wslot, (int)lane == wl, out.c);
-                    if (lane == 0) {
-                        out.b1 = wmin;
-                        out.i1 = wmin < __builtin_inf() ? (uint32_t)ss.idx_tab[wslot < (uint32_t)S ? wslot : 0][(wave << 6) + (uint32_t)wl] : kNoNode;
-                        out.amb_nc = (nc << 1) | wamb;
-                        lds_bump(&sh.done[slot]);
+                }
+                const uint64_t any_rows = rows[0] | rows[1] | rows[2] | rows[3];
+                if (STAMP) ts_rows += (uint64_t)__popcll(rows[0]);
+                Scan sc[kBatch];
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b) sc[b] = Scan{__builtin_inf(), 0u, 0xFFFFFFFFu};
+                // ---- scan: static loop over the rows, wave-uniform branches on the selection bits
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if ((any_rows >> s) & 1ull) {
+                        double c[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) c[k] = tr[k][s];
+#pragma unroll
+                        for (int b = 0; b < kBatch; ++b) {
+#if OXHIP_PRUNE_PER_QUERY
+                            if ((rows[b] >> s) & 1ull)
+#endif
+                                scan_push(sc[b], dist2<D>(c, q[b], DIM), (uint32_t)s);
+                        }
                     }
                 }
                 if (STAMP) { uint64_t now = (uint64_t)clock64(); ts_scan += now - t_mark; t_mark = now; }
+                // ---- reduce + publish (d2, index, near-tie flag); the resolver fetches coordinates itself (node_coord)
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b) {
+                    if ((uint32_t)b < nb) {
+                        const uint32_t slot = (j + (uint32_t)b) & (kRing - 1);
+                        const double wmin = wave_min_f64(sc[b].b1);
+                        const uint64_t eqm = __ballot(sc[b].b1 == wmin);
+                        const int wl = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
+                        const uint32_t wslot = __builtin_amdgcn_readlane(sc[b].slot, wl);
+                        const uint32_t hb = hi32(wmin) + 1;
+                        const bool amb_l = ((int)lane != wl && hi32(sc[b].b1) <= hb) || (sc[b].h2 <= hb);
+                        const uint32_t wamb = __ballot(amb_l) != 0 ? 1u : 0u;
+                        if (lane == 0) {
+                            WavePub<DIM>& out = sh.pub[slot][wave];
+                            out.b1 = wmin;
+                            out.i1 = wmin < __builtin_inf() ? (uint32_t)ss.idx_tab[wslot < (uint32_t)S ? wslot : 0][(wave << 6) + (uint32_t)wl] : kNoNode;
+                            out.amb_nc = (nc << 1) | wamb;
+                            lds_bump(&sh.done[slot]);
+                        }
+                    }
+                }
                 j += nb;
                 if (STAMP) { uint64_t now = (uint64_t)clock64(); ts_red += now - t_mark; t_mark = now; }
             }
@@ -388,7 +440,8 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
             double dist_or_g;
             if (!amb) {
     #pragma unroll
-                for (int k = 0; k < D; ++k) q_near[k] = from_scan ? unid(sh.pub[slot][wl].c[k]) : unid(sh.newn[wl][k]);
+                for (int k = 0; k < D; ++k)
+                    q_near[k] = from_scan ? unid(node_coord_p<DIM>(sh, tree, cap, st0.n_nodes, n, k, nearest)) : unid(sh.newn[wl][k]);
                 dist_or_g = g;
                 dup = g == 0.0;
             } else {
@@ -521,7 +574,9 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
                 const bool amb_r = ((uint32_t)(__ballot(amb_l) >> (16 * row)) & 0xFFFFu) != 0 || (rowS == 0 && rowP == 0);
                 double q_near[D], qn[D], mid[D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) q_near[k] = from_scan ? sh.pub[slot_r][wsub].c[k] : sh.newn[nearest_r & 63][k];
+                for (int k = 0; k < D; ++k)
+                    q_near[k] = from_scan ? node_coord_p<DIM>(sh, tree, cap, st0.n_nodes, n0q, k, active && nearest_r != kNoNode ? nearest_r : 0u)
+                                          : sh.newn[nearest_r & 63][k];
                 steer<DIM>(p, false, g_r, q_near, q, qn);
                 lerp<DIM>(q_near, qn, 0.5, mid, DIM);
                 bool maybe_l = false;
