@@ -129,20 +129,45 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                 }
             }
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_scan += now - t_mark; t_mark = now; }
-            // reduce: branch-free for the whole batch, so the kBatch DPP chains / ballots interleave
+            // reduce.  d2 >= +0, so its high dword orders like the value: the wave minimum of the HIGH DWORDS (a 32-bit
+            // DPP chain, half the work of the 64-bit one) names the winner outright whenever exactly one lane's best
+            // lies within one high-dword step of it and no lane saw a second value that close -- which is also
+            // precisely the "unambiguous" verdict.  Only otherwise (near-ties, an all-empty wave: ~1e-3 of passes)
+            // the full 64-bit minimum and tie analysis run.  The four chains of a pass interleave; one branch per pass.
             double wmin[kBatch];
             int wl[kBatch];
             uint32_t wslot[kBatch], wamb[kBatch];
+            uint32_t mh[kBatch];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) wmin[b] = wave_min_f64(sc[b].b1);
+            for (int b = 0; b < kBatch; ++b) mh[b] = wave_min_u32(hi32(sc[b].b1));
+            uint64_t nearA[kBatch];
+            bool fast = true;
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
-                const uint64_t eqm = __ballot(sc[b].b1 == wmin[b]);
-                wl[b] = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
-                wslot[b] = __builtin_amdgcn_readlane(sc[b].slot, wl[b]);
-                const uint32_t hb = hi32(wmin[b]) + 1;
-                const bool amb_l = ((int)lane != wl[b] && hi32(sc[b].b1) <= hb) || (sc[b].h2 <= hb);
-                wamb[b] = __ballot(amb_l) != 0 ? 1u : 0u;
+                nearA[b] = __ballot(hi32(sc[b].b1) <= mh[b] + 1u);
+                const uint64_t nearB = __ballot(sc[b].h2 <= mh[b] + 1u);
+                fast = fast && __popcll(nearA[b]) == 1 && nearB == 0;
+            }
+            if (fast) {
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b) {
+                    wl[b] = __ffsll((unsigned long long)nearA[b]) - 1;
+                    wmin[b] = readlane_f64(sc[b].b1, wl[b]);
+                    wslot[b] = __builtin_amdgcn_readlane(sc[b].slot, wl[b]);
+                    wamb[b] = 0u;
+                }
+            } else {
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b) wmin[b] = wave_min_f64(sc[b].b1);
+#pragma unroll
+                for (int b = 0; b < kBatch; ++b) {
+                    const uint64_t eqm = __ballot(sc[b].b1 == wmin[b]);
+                    wl[b] = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
+                    wslot[b] = __builtin_amdgcn_readlane(sc[b].slot, wl[b]);
+                    const uint32_t hb = hi32(wmin[b]) + 1;
+                    const bool amb_l = ((int)lane != wl[b] && hi32(sc[b].b1) <= hb) || (sc[b].h2 <= hb);
+                    wamb[b] = __ballot(amb_l) != 0 ? 1u : 0u;
+                }
             }
             // publish: the owning lane stores the coordinates, lane 0 the 16-byte head, then the slot is counted
 #pragma unroll
