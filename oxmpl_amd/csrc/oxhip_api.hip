@@ -109,10 +109,8 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         th_lo = th_lo > -pi ? th_lo : -pi;
         th_hi = th_hi < pi ? th_hi : pi;
         // extent = extent_xy + 0.5 * PI (so2_state_space.rs:78-80); lvsl = extent * fraction; res = lvsl * 0.1
-        int32_t sr = space_resolution(2, cfg->bounds, fraction, res);
+        int32_t sr = space_resolution(2, cfg->bounds, fraction, res);   // validates the (x, y) bounds, clamps the fraction
         if (sr != OXHIP_OK) return sr;
-        const double lvsl_xy10 = res;          // (extent_xy * fraction) * 0.1: recompute from the extent itself
-        (void)lvsl_xy10;
         double acc = 0.0;
         for (uint32_t k = 0; k < 2; ++k) { double w = cfg->bounds[2 * k + 1] - cfg->bounds[2 * k]; double sq = w * w; acc = acc + sq; }
         const double extent = std::sqrt(acc) + 0.5 * pi;
