@@ -242,7 +242,8 @@ typedef struct oxhip_prm_config {
     double   lvs_fraction;              /* longest_valid_segment_fraction, default 0.05 */
     uint32_t max_milestones;            /* construct_roadmap stops at this many milestones (build-defined) */
     int32_t  device;                    /* HIP device ordinal */
-    uint64_t max_samples;               /* ... or after this many sample_uniform calls; 0 = unlimited */
+    uint64_t max_samples;               /* ... or after this many sample_uniform calls; 0 = 4096 * max_milestones + 2^22
+                                           (so that a space with no valid state still returns) */
     uint64_t seed;                      /* ChaCha12 key = LE(seed)||0^24 */
     uint64_t stream;                    /* ChaCha12 stream id */
 } oxhip_prm_config;

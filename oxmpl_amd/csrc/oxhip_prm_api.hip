@@ -292,7 +292,8 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
     const auto t0 = std::chrono::steady_clock::now();
     const bool has_timeout = h->cfg.timeout > 0.0 && std::isfinite(h->cfg.timeout);
     const uint32_t n_max = h->cfg.max_milestones;
-    const uint64_t max_samples = h->cfg.max_samples ? h->cfg.max_samples : ~0ull;
+    // 0 = "unlimited", which still has to end when (almost) no sample is valid: 4096 draws per requested milestone
+    const uint64_t max_samples = h->cfg.max_samples ? h->cfg.max_samples : 4096ull * n_max + (1ull << 22);
     for (double& t : h->t_ms) t = 0.0;
     h->n_candidates = 0;
     PrmState st{};

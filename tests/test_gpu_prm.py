@@ -257,3 +257,15 @@ def test_prm_many_spheres_filter_is_conservative(dim, n_spheres, rmax):
     t = g.last_timing()
     assert 2 * t["candidates"] > len(gn) > 0      # some in-radius pairs were rejected by check_motion
     assert_same_query(g, o)
+
+
+def test_prm_fully_blocked_space_returns_an_empty_roadmap():
+    """no sample is ever valid: construct_roadmap must still return (the reference would run into its timeout)"""
+    P = dict(dim=2, bounds=[(0.0, 1.0), (0.0, 1.0)], radius=0.5, fraction=0.05, seed=1, stream=1, max_milestones=50,
+             max_samples=10 ** 9, boxes=[([-1.0, -1.0], [2.0, 2.0])], spheres=[])
+    g = make_gpu_prm(P)
+    g.setup([0.5, 0.5], [0.6, 0.6], 0.1)
+    g.construct_roadmap()
+    n, e, s = g.sizes()
+    assert n == 0 and e == 0 and s == 4096 * 50 + (1 << 22)
+    assert g.solve()[0] == capi.ERR_UNSAMPLED_STATE_SPACE
