@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--strong-total", type=int, default=0,
                     help="strong scaling: this many problems in total, divided over the ranks (SURVEY.md 8(d): 8192)")
     ap.add_argument("--iters", type=int, default=4096, help="RRT iterations per problem per step")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident, 3 resident + pruned scan")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident, 3 resident + pruned scan, 4 resident + binary32 screen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stream-kernel measurement")
     args = ap.parse_args()
@@ -149,7 +149,7 @@ def main():
     assert done == P * args.iters * (args.steps + args.warmup)
     iters_timed = P * args.iters * args.steps
 
-    kname = {1: "stream", 2: "resident", 3: "pruned"}[gpu.last_timing()["kernel"]]
+    kname = {1: "stream", 2: "resident", 3: "pruned", 4: "resident_f32"}[gpu.last_timing()["kernel"]]
     # secondary (rank 0, N=1 only): the HBM-streaming kernel on the same workload, 2 steps
     secondary = None
     if world == 1 and not args.no_secondary and kname != "stream":

@@ -74,7 +74,9 @@ typedef enum oxhip_kernel_kind {
     OXHIP_KERNEL_AUTO = 0,      /* resident when the tree fits the register file, else streaming */
     OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
     OXHIP_KERNEL_RESIDENT = 2,  /* tree held in the workgroup's vector registers, every node scanned */
-    OXHIP_KERNEL_PRUNED = 3     /* resident + spatially sorted rows with bounding boxes: exact pruned scan */
+    OXHIP_KERNEL_PRUNED = 3,    /* resident + spatially sorted rows with bounding boxes: exact pruned scan */
+    OXHIP_KERNEL_RESIDENT_F32 = 4 /* resident, the scanners screen in packed binary32 and the resolver decides in binary64
+                                     from the binary64 nodes: same results bit for bit (rrt_resident32.hip) */
 } oxhip_kernel_kind;
 
 /* RRT::new(max_distance, goal_bias) (rrt.rs:75-83) + RealVectorStateSpace::new(dim, bounds)

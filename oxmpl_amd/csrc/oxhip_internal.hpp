@@ -41,6 +41,10 @@ void launch_rrt_star(const DevParams& p, hipStream_t stream);
 bool resident_supported(uint32_t dim, uint32_t cap);
 void launch_rrt_resident(const DevParams& p, hipStream_t stream);
 
+// rrt_resident32.hip: the resident pipeline with a binary32 screen in the scanner waves (exact results)
+bool resident32_supported(uint32_t dim, uint32_t cap);
+void launch_rrt_resident32(const DevParams& p, hipStream_t stream);
+
 // rrt_pruned.hip: the resident pipeline + launch-time spatial sort and box-pruned scans
 bool pruned_supported(uint32_t dim, uint32_t cap);
 void launch_rrt_pruned(const DevParams& p, hipStream_t stream);

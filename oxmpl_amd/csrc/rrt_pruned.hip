@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
             double mid[D];
             lerp<DIM>(q_near, q_new, 0.5, mid, DIM);
             if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid)) == 0 && !extras) return true;
-            return motion_full<DIM>(p, lane, q_near, q_new, oc, othr, ns64);
+            return motion_lanes<DIM>(p, lane, q_near, q_new, oc, othr, ofilt, ns64);
         };
 
 
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_pruned_kernel(DevParams p) {
                                 double qnr[D];
 #pragma unroll
                                 for (int k = 0; k < D; ++k) qnr[k] = readlane_f64(q_near[k], l0);
-                                ok = motion_full<DIM>(p, lane, qnr, q_new, oc, othr, ns64);
+                                ok = motion_lanes<DIM>(p, lane, qnr, q_new, oc, othr, ofilt, ns64);
                             }
                         }
                         uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);

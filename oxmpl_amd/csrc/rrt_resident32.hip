@@ -1,12 +1,29 @@
-// rrt_resident.hip -- register-resident RRT grow kernel for gfx950 (the fast path).
+// rrt_resident32.hip -- the register-resident RRT grow kernel with a binary32 SCREEN in the scanners.
 //
-// A 10,240-node R^3 tree is 240 KB: too big for LDS (160 KB) but it fits the 512 KB vector
-// register file of one CU.  One 576-thread workgroup per problem: 8 scanner waves hold the tree in
-// VGPRs (126 VGPRs for R^3) and stream queries from an LDS ring, so the O(n) nearest-neighbour scan
-// of rrt.rs:187-196 reads no memory at all and is bounded by f64 VALU issue; one resolver wave
-// samples ahead, consumes the scanners' candidates in order, steers, checks the motion and commits.
-// No workgroup barrier in steady state (see "Asynchronous pipeline" below).  The SoA tree in HBM
-// is only the persistent copy: written once per insert, read once per launch.
+// Same pipeline as rrt_resident.hip (8 scanner waves + 1 resolver wave per problem, LDS query ring, no
+// workgroup barrier in steady state).  The difference is what the scanner waves hold and compute:
+//   * the tree sits in VGPRs as binary32 roundings of the binary64 nodes (63 VGPRs for 10,240 nodes in R^3
+//     instead of 126), and the O(n) scan of rrt.rs:187-196 runs in packed binary32 (v_pk_add/mul/fma_f32: two
+//     queries per instruction) with the slot number folded into the low 5 bits of the squared distance, so the
+//     per-lane bookkeeping is one v_and_or, one v_med3_u32 (second smallest) and one v_min_u32 per (node, query);
+//   * that scan only SCREENS.  Each wave publishes its smallest and second smallest key; the resolver bounds the
+//     true binary64 distance of every screened node from its key (error model below) and accepts the scan's
+//     winner only when the runner-up is provably farther.  The winner's distance, the steer, the motion check
+//     and the comparison with the nodes committed after the scan's snapshot are then computed in binary64 from
+//     the binary64 node exactly as in rrt_resident.hip.  When the screen cannot separate winner and runner-up
+//     (~1e-4 of queries) the resolver runs the reference's own loop over the binary64 tree in HBM / L2.
+// The result is bit-identical to the binary64 kernels (and to the oracle); only the work to find it shrinks.
+//
+// Error model (u = 2^-24; M = largest coordinate magnitude among the bounds, the goal centre and the tree: every
+// query is a sample inside the bounds or the goal centre, every new node a convex combination of two of those):
+//   e_k = fl32(fl32(q_k) - fl32(c_k))             |e_k - (q_k - c_k)| <= u|q_k| + u|c_k| + u|e_k|  <= 4.1 u M
+//   s   = fma(e_2,e_2, fma(e_1,e_1, e_0*e_0))     s = |e|^2 (1 + eta) + zeta, |eta| <= D u, |zeta| <= D 2^-126
+//   key = bits(s) with the low 5 bits replaced     value(key) <= s < value(key) (1 + 2^-18)
+// so the true distance d of a node with key value v obeys
+//   sqrt(v) (1 - R) - A  <=  d  <=  sqrt(v) (1 + R) + A,   A = sqrt(D) 4.1 u M + 1e-18,  R = 2^-19 + (D + 2) u.
+// The kernel uses 2A and 2R (+ 2^-21 for taking sqrt(v) in binary32).  A winner is accepted when  sqrt(v2)(1 - 2R) - 2A  >  sqrt(v1)(1 + 2R) + 2A : every
+// other screened node is then farther by at least ~1e-7 M, eleven orders of magnitude above the rounding of the
+// binary64 post-sqrt compare of rrt.rs:192, so strict-'<' / lowest-index semantics cannot be involved.
 //
 // Replaces the loop body of RRT::solve, oxmpl/src/geometric/planners/rrt.rs:170-225.
 #include "oxhip_internal.hpp"
@@ -14,27 +31,96 @@
 #include "rrt_resident_common.hpp"
 
 namespace oxhip {
-// Coordinates of node i for the resolver.  The scanners publish only (d2, index): copying the winning slot out of a
-// register array costs every scanner wave a 21-way uniform branch ladder per query (~180 scalar instructions), and
-// seven of eight waves lose anyway (167.7 -> 189.4 M it/s without it).  The resolver fetches the one node it needs:
-// from the LDS ring of the last 64 commits when the node is that young (its HBM store may still be in flight),
-// else from the persistent copy in HBM / L2, which this same wave wrote at least 64 commits -- and several
-// `s_waitcnt vmcnt(0)` -- ago, or which predates the launch.
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr uint32_t kKeyInf = 0x7F80001Fu;   // +inf with slot 31: "no node"
+constexpr uint32_t kSlotMask = 31u;
+
+struct alignas(16) WavePub32 {   // one wave's screen result for one query (one 16-byte LDS store)
+    uint32_t k1;   // smallest key of the wave
+    uint32_t k2;   // second smallest key of the wave (with multiplicity)
+    uint32_t i1;   // node index of k1
+    uint32_t nc;   // tree size this scan covered (the wave's snapshot of `committed`)
+};
+
 template <int DIM>
-__device__ __forceinline__ double node_coord(const PipeShared<DIM>& sh, const double* tree, size_t cap, uint32_t n_start,
-                                             uint32_t n_now, int k, uint32_t i) {
+struct PipeShared32 {
+    uint32_t rng_buf[16][64];
+    QSlot<DIM> qring[kRing];
+    WavePub32 pub[kRing][kScanWaves];
+    uint32_t done[kRing];
+    double newn[64][DIM];
+    double obs[DIM + 1][64];
+    uint32_t sampled, resolved, committed, stop_flag;
+    uint32_t mabs_bits;                  // bits of the largest |fl32(coordinate)| the scanners loaded
+};
+
+template <int DIM>
+__device__ __forceinline__ double node_coord32(const PipeShared32<DIM>& sh, const double* tree, size_t cap, uint32_t n_start,
+                                               uint32_t n_now, int k, uint32_t i) {
     if (i >= n_start && i + 64u >= n_now) return sh.newn[i & 63][k];
     return __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ uint32_t f32_bits(float v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ float bits_f32(uint32_t v) { return __builtin_bit_cast(float, v); }
+
+// per-lane screen state of one query
+struct Screen {
+    uint32_t b1;   // smallest key
+    uint32_t h2;   // second smallest key (with multiplicity)
+};
+__device__ __forceinline__ void screen_push(Screen& v, float s, uint32_t slot) {
+    const uint32_t key = (f32_bits(s) & ~kSlotMask) | slot;
+    v.h2 = umed3(key, v.b1, v.h2);
+    v.b1 = key < v.b1 ? key : v.b1;
+}
+
+// The resolver's view of one query's screen, for the 16-lane DPP row the caller sits in (lanes sub < 8 read the
+// eight waves' results).  Row-uniform outputs.
+struct RowScreen {
+    uint32_t cand;    // the screen's winner (node index; meaningful when clear)
+    uint32_t bmin;    // oldest scan snapshot among the eight waves
+    bool clear;       // the winner is provably the nearest of all screened nodes
+};
+struct Margins {
+    double a2;        // 2A
+    double r_lo;      // 1 - 2R
+    double r_hi;      // 1 + 2R
+    bool usable;      // M small enough for binary32 squares
+};
+__device__ __forceinline__ RowScreen row_screen(const WavePub32* pubs, uint32_t row, uint32_t sub, bool active, const Margins& mg) {
+    const bool inS = active && sub < (uint32_t)kScanWaves;
+    const WavePub32 mine = pubs[inS ? sub : 0];
+    const uint32_t k1 = inS ? mine.k1 : kKeyInf;
+    const uint32_t k2 = inS ? mine.k2 : kKeyInf;
+    const uint32_t nc = inS ? mine.nc : 0xFFFFFFFFu;
+    const uint32_t K1 = row_min_u32(k1);
+    const uint32_t eq = (uint32_t)(__ballot(inS && k1 == K1) >> (16 * row)) & 0xFFFFu;
+    const uint32_t wsub = eq ? (uint32_t)(__ffs((int)eq) - 1) : 0u;
+    const uint32_t K2 = row_min_u32((inS && sub == wsub) ? k2 : k1);
+    RowScreen r;
+    r.cand = (uint32_t)__shfl((int)mine.i1, (int)(16 * row + wsub), 64);
+    r.bmin = row_min_u32(nc);
+    const float v1 = bits_f32(K1 & ~kSlotMask), v2 = bits_f32(K2 & ~kSlotMask);
+    // v_sqrt_f32 (1 ulp; a subnormal argument may come back as 0, which the 1e-18 inside A covers): its 2^-22 is in r_lo / r_hi
+    const double d1 = (double)__builtin_amdgcn_sqrtf(v1), d2 = (double)__builtin_amdgcn_sqrtf(v2);
+    // (+inf second: d2 = +inf and the test holds; +inf or NaN first: it fails)
+    r.clear = mg.usable && eq != 0 && (d2 * mg.r_lo - mg.a2 > d1 * mg.r_hi + mg.a2);
+    return r;
+}
+
 template <int DIM, int S, bool STAMP>
-__global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p) {
+__global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams p) {
     constexpr int D = DIM;
+    static_assert(S <= 32, "the slot number lives in 5 key bits");
+    static_assert(kBatch % 2 == 0, "queries are screened in pairs");
     const uint32_t prob = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = uni(tid >> 6), lane = tid & 63;
 
-    __shared__ PipeShared<DIM> sh;
+    __shared__ PipeShared32<DIM> sh;
 
     const ProblemState st0 = p.state[prob];
     if (p.stop_at_goal && st0.goal_node >= 0) return;
@@ -51,26 +137,35 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         sh.resolved = 0;
         sh.committed = st0.n_nodes;
         sh.stop_flag = 0;
+        sh.mabs_bits = 0;
     }
-    __syncthreads();  // the only workgroup barrier of the launch
+    __syncthreads();
 
     if (wave < kScanWaves) {
         // ================================================================= scanner waves
         using Lay = Layout<S>;
         uint32_t n_local = st0.n_nodes;
-        double tr[DIM][S];
+        float tr[DIM][S];
+        uint32_t mab = 0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const uint32_t i = ((uint32_t)s < Lay::kCommon || Lay::heavy(wave)) ? Lay::node_index(wave, lane, (uint32_t)s) : kNoNode;
-            const bool live = i < n_local && skip[i] == 0;  // duplicates of a lower-index node never win: hold +inf
+            const bool in_tree = i < n_local;
+            const bool live = in_tree && skip[i] == 0;  // duplicates of a lower-index node never win: hold +inf
 #pragma unroll
-            for (int k = 0; k < DIM; ++k) tr[k][s] = live ? tree[(size_t)k * cap + i] : __builtin_inf();
+            for (int k = 0; k < DIM; ++k) {
+                const float f = in_tree ? (float)tree[(size_t)k * cap + i] : 0.0f;
+                const uint32_t ab = f32_bits(f) & 0x7FFFFFFFu;
+                mab = ab > mab ? ab : mab;
+                tr[k][s] = live ? f : __builtin_inff();
+            }
         }
+        __hip_atomic_fetch_max(&sh.mabs_bits, mab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();  // the resolver reads mabs_bits after this barrier (the second and last of the launch)
+
         uint64_t t_wait = 0, t_work = 0, t_pre = 0, t_scan = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
         uint32_t seen_sampled = 0;
         for (uint32_t j = 0; j < budget; j += kBatch) {
-            // one pass scans kBatch queries (the tail pass may hold one): fixed costs are shared, the two
-            // reductions are independent dependency chains
             const uint32_t nb = (budget - j < (uint32_t)kBatch) ? (budget - j) : (uint32_t)kBatch;
             const uint32_t need = j + nb;
             // wait until the pass's queries are sampled (implies their ring slots were consumed kRing queries ago)
@@ -93,93 +188,69 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                     if (sl == (uint32_t)s) {
                         if (mine) {
 #pragma unroll
-                            for (int k = 0; k < D; ++k) tr[k][s] = sh.newn[i & 63][k];
+                            for (int k = 0; k < D; ++k) tr[k][s] = (float)sh.newn[i & 63][k];   // +inf stays +inf
                         }
                     }
                 }
             }
             n_local = nc;
-            double q[kBatch][D];
+            // the pass's queries, two per packed register
+            f32x2 q[kBatch / 2][D];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
                 const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kRing - 1);
 #pragma unroll
-                for (int k = 0; k < D; ++k) q[b][k] = unid(sh.qring[slot].q[k]);
+                for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = (float)unid(sh.qring[slot].q[k]);
             }
-            // nearest neighbour over this wave's nodes (rrt.rs:187-196), d2 compare
             const uint32_t nslots = Lay::slots_in_use(wave, nc);
-            Scan sc[kBatch];
+            Screen sc[kBatch];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) sc[b] = Scan{__builtin_inf(), 0u, 0xFFFFFFFFu};
+            for (int b = 0; b < kBatch; ++b) sc[b] = Screen{kKeyInf, kKeyInf};
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_pre += now - t_mark; t_mark = now; }
-            // slots are visited in groups of kGroup under ONE uniform branch: inside a group the code is
-            // straight-line, so the scheduler interleaves kGroup x kBatch independent sub/mul/add chains
-            // (empty slots hold +inf and can never win)
+            // screen (rrt.rs:187-196 in binary32): groups of kGroup slots under one uniform branch
 #pragma unroll
             for (int g0 = 0; g0 < S; g0 += group_len<S>(g0)) {
                 if ((uint32_t)g0 < nslots) {
 #pragma unroll
                     for (int s = g0; s < g0 + group_len<S>(g0); ++s) {
-                        double c[D];
 #pragma unroll
-                        for (int k = 0; k < D; ++k) c[k] = tr[k][s];
+                        for (int bp = 0; bp < kBatch / 2; ++bp) {
+                            f32x2 e = (f32x2){tr[0][s], tr[0][s]} - q[bp][0];
+                            f32x2 acc = e * e;
 #pragma unroll
-                        for (int b = 0; b < kBatch; ++b) scan_push(sc[b], dist2<D>(c, q[b], DIM), (uint32_t)s);
+                            for (int k = 1; k < D; ++k) {
+                                e = (f32x2){tr[k][s], tr[k][s]} - q[bp][k];
+                                acc = __builtin_elementwise_fma(e, e, acc);
+                            }
+                            screen_push(sc[2 * bp], acc[0], (uint32_t)s);
+                            screen_push(sc[2 * bp + 1], acc[1], (uint32_t)s);
+                        }
                     }
                 }
             }
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_scan += now - t_mark; t_mark = now; }
-            // reduce.  d2 >= +0, so its high dword orders like the value: the wave minimum of the HIGH DWORDS (a 32-bit
-            // DPP chain, half the work of the 64-bit one) names the winner outright whenever exactly one lane's best
-            // lies within one high-dword step of it and no lane saw a second value that close -- which is also
-            // precisely the "unambiguous" verdict.  Only otherwise (near-ties, an all-empty wave: ~1e-3 of passes)
-            // the full 64-bit minimum and tie analysis run.  The four chains of a pass interleave; one branch per pass.
-            double wmin[kBatch];
+            // reduce: the wave's smallest key, its lane, and the smallest of everything else
+            uint32_t k1w[kBatch], k2w[kBatch];
             int wl[kBatch];
-            uint32_t wslot[kBatch], wamb[kBatch];
-            uint32_t mh[kBatch];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) mh[b] = wave_min_u32(hi32(sc[b].b1));
-            uint64_t nearA[kBatch];
-            bool fast = true;
+            for (int b = 0; b < kBatch; ++b) k1w[b] = wave_min_u32(sc[b].b1);
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
-                nearA[b] = __ballot(hi32(sc[b].b1) <= mh[b] + 1u);
-                const uint64_t nearB = __ballot(sc[b].h2 <= mh[b] + 1u);
-                fast = fast && __popcll(nearA[b]) == 1 && nearB == 0;
+                const uint64_t eqm = __ballot(sc[b].b1 == k1w[b]);
+                wl[b] = __ffsll((unsigned long long)eqm) - 1;   // eqm != 0: the minimum is attained
+                k2w[b] = wave_min_u32((int)lane == wl[b] ? sc[b].h2 : sc[b].b1);
             }
-            if (fast) {
-#pragma unroll
-                for (int b = 0; b < kBatch; ++b) {
-                    wl[b] = __ffsll((unsigned long long)nearA[b]) - 1;
-                    wmin[b] = readlane_f64(sc[b].b1, wl[b]);
-                    wslot[b] = __builtin_amdgcn_readlane(sc[b].slot, wl[b]);
-                    wamb[b] = 0u;
-                }
-            } else {
-#pragma unroll
-                for (int b = 0; b < kBatch; ++b) wmin[b] = wave_min_f64(sc[b].b1);
-#pragma unroll
-                for (int b = 0; b < kBatch; ++b) {
-                    const uint64_t eqm = __ballot(sc[b].b1 == wmin[b]);
-                    wl[b] = eqm ? (__ffsll((unsigned long long)eqm) - 1) : 0;
-                    wslot[b] = __builtin_amdgcn_readlane(sc[b].slot, wl[b]);
-                    const uint32_t hb = hi32(wmin[b]) + 1;
-                    const bool amb_l = ((int)lane != wl[b] && hi32(sc[b].b1) <= hb) || (sc[b].h2 <= hb);
-                    wamb[b] = __ballot(amb_l) != 0 ? 1u : 0u;
-                }
-            }
-            // publish: the owning lane stores the coordinates, lane 0 the 16-byte head, then the slot is counted
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
                 if ((uint32_t)b < nb) {
                     const uint32_t slot = (j + (uint32_t)b) & (kRing - 1);
-                    WavePub<DIM>& out = sh.pub[slot][wave];
-                    // (the candidate's coordinates are not published: see node_coord)
                     if (lane == 0) {
-                        out.b1 = wmin[b];
-                        out.i1 = Lay::node_index(wave, (uint32_t)wl[b], wslot[b]);
-                        out.amb_nc = (nc << 1) | wamb[b];
+                        WavePub32 out;
+                        out.k1 = k1w[b];
+                        out.k2 = k2w[b];
+                        out.i1 = Lay::node_index(wave, (uint32_t)wl[b], k1w[b] & kSlotMask);
+                        out.nc = nc;
+                        sh.pub[slot][wave] = out;
                         lds_bump(&sh.done[slot]);
                     }
                 }
@@ -204,7 +275,6 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
     const uint32_t nobs = p.n_spheres + p.n_boxes;
     const uint32_t ns64 = p.n_spheres < 64 ? p.n_spheres : 64;
     const bool extras = nobs > ns64;  // spheres beyond the first 64 and every box: always stepped, never filtered
-    // this lane's obstacle (unused lanes hold a sphere that can never be hit), also mirrored to LDS
     double oc[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) oc[k] = lane < ns64 ? p.sph_c[(size_t)k * p.n_spheres + lane] : 0.0;
@@ -223,20 +293,43 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
     const uint32_t row = lane >> 4, sub = lane & 15;
     uint64_t t_wait = 0, t_work = 0, t_samp = 0, t_comb = 0, n_amb = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
 
+    __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
+    Margins mg;
+    {
+        // M: the tree as loaded (binary32 roundings, hence the 1 + 2^-23), the bounds and the goal centre
+        double m = (double)bits_f32(lds_peek(&sh.mabs_bits)) * (1.0 + 0x1p-23);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            m = fmax(m, fmax(fabs(p.lo[k]), fabs(p.hi[k])));
+            m = fmax(m, fabs(goal_c[k]));
+        }
+        m = unid(m) * 1.001;   // interpolation rounding over any chain of inserts
+        const double u = 0x1p-24;
+        mg.usable = m < 1e15;  // also false for NaN / inf
+        mg.a2 = 2.0 * (sqrt((double)D) * 4.1 * u * m + 1e-18);
+        const double r2 = 2.0 * (0x1p-19 + (double)(D + 2) * u) + 0x1p-21;   // + the binary32 square root of row_screen
+        mg.r_lo = 1.0 - r2;
+        mg.r_hi = 1.0 + r2;
+    }
+
     // ---- one query, the reference's sequential semantics in full (tails, batch conflicts, near-ties):
-    //      candidates = the 8 scanner waves' + every node committed after the oldest scan snapshot
+    //      candidates = the screen's winner + every node committed after the oldest scan snapshot
     auto resolve_one = [&](uint32_t jq, uint32_t& nearest, double (&q_new)[D], bool& dup) -> bool {
         const uint32_t slot = jq & (kRing - 1);
         double q[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) q[k] = unid(sh.qring[slot].q[k]);
-        const bool inS = lane < (uint32_t)kScanWaves;
-        const WavePub<DIM>& mine = sh.pub[slot][inS ? lane : 0];
-        const double pb = inS ? mine.b1 : __builtin_inf();
-        const uint32_t pan = inS ? mine.amb_nc : 0xFFFFFFFFu;
-        const uint32_t pamb = inS ? (pan & 1u) : 0u;
-        const uint32_t pidxS = inS ? mine.i1 : kNoNode;
-        const uint32_t base_min = wave_min_u32(pan >> 1);  // oldest snapshot among the 8 scans
+        // every row evaluates the same query's screen: the outputs are wave-uniform
+        const RowScreen rs = row_screen(sh.pub[slot], row, sub, true, mg);
+        const bool clear = __builtin_amdgcn_readfirstlane(rs.clear ? 1 : 0) != 0;
+        const uint32_t cand = uni(rs.cand);
+        const uint32_t base_min = uni(rs.bmin);
+        double cc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) cc[k] = clear ? unid(node_coord32<DIM>(sh, tree, cap, st0.n_nodes, n, k, cand < n ? cand : 0u)) : 0.0;
+        const bool inS = lane == 0;   // lane 0 carries the screen's winner with its binary64 d2
+        const double pb = (inS && clear) ? dist2<D>(cc, q, DIM) : __builtin_inf();
+        const uint32_t pidxS = inS ? cand : kNoNode;
         // the ring entry of this lane holds the latest node i with (i & 63) == lane
         uint32_t pidx = kNoNode;
         if (n > lane) {
@@ -250,26 +343,24 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         const double d2p = pv ? dist2<D>(pn, q, DIM) : __builtin_inf();
         const double g = wave_min_f64(d2p < pb ? d2p : pb);
         const uint32_t hb = hi32(g) + 1;
-        const bool nearS = inS && hi32(pb) <= hb;
+        const bool nearS = inS && clear && hi32(pb) <= hb;
         const bool nearP = pv && hi32(d2p) <= hb;
         const uint64_t mS = __ballot(nearS), mP = __ballot(nearP);
         const bool from_scan = mS != 0;
-        const int wl = from_scan ? (__ffsll((unsigned long long)mS) - 1) : (mP ? (__ffsll((unsigned long long)mP) - 1) : 0);
-        nearest = from_scan ? (uint32_t)__builtin_amdgcn_readlane((int)pidxS, wl)
-                            : (uint32_t)__builtin_amdgcn_readlane((int)pidx, wl);
-        // unambiguous iff every near candidate is that one node and no near wave saw a second near node
-        const bool amb = __ballot((nearS && (pidxS != nearest || pamb != 0)) || (nearP && pidx != nearest)) != 0;
+        const int wl = from_scan ? 0 : (mP ? (__ffsll((unsigned long long)mP) - 1) : 0);
+        nearest = from_scan ? cand : (uint32_t)__builtin_amdgcn_readlane((int)pidx, wl);
+        // unambiguous iff the screen was clear and every near candidate is that one node
+        const bool amb = !clear || (mS == 0 && mP == 0) || __ballot((nearS && pidxS != nearest) || (nearP && pidx != nearest)) != 0;
         double q_near[D];
         double dist_or_g;
         if (!amb) {
 #pragma unroll
-            for (int k = 0; k < D; ++k)
-                q_near[k] = from_scan ? unid(node_coord<DIM>(sh, tree, cap, st0.n_nodes, n, k, nearest)) : unid(sh.newn[wl][k]);
+            for (int k = 0; k < D; ++k) q_near[k] = from_scan ? cc[k] : unid(sh.newn[wl][k]);
             dist_or_g = g;
             dup = g == 0.0;
         } else {
-            // rare (~1e-6 of queries): the reference's own loop -- post-sqrt compare with lowest-index ties --
-            // over the persistent copy of the tree in global memory
+            // the reference's own loop -- post-sqrt compare with lowest-index ties -- over the persistent
+            // binary64 copy of the tree in global memory
             if (STAMP) ++n_amb;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -304,7 +395,6 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         if (js < budget && js - jr <= (uint32_t)(kRing / 2)) {
             uint32_t m = jr + kRing - js;  // free ring slots
             if (m > budget - js) m = budget - js;
-            // keep the batch's words inside the LDS window: refill (64 blocks from the current position) when short
             const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + D) + 64;
             if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
                 rng.base_blk = uni64(rng.pos >> 3);
@@ -350,14 +440,18 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
 #pragma unroll
         for (int k = 0; k < D; ++k) q[k] = sh.qring[slot_r].q[k];
         const uint64_t pos_after_r = sh.qring[slot_r].pos_after;
-        const bool inS = active && sub < (uint32_t)kScanWaves;
-        const WavePub<DIM>& mine = sh.pub[slot_r][inS ? sub : 0];
-        const double pb = inS ? mine.b1 : __builtin_inf();
-        const uint32_t pan = inS ? mine.amb_nc : 0xFFFFFFFFu;
-        const uint32_t pidxS = inS ? mine.i1 : kNoNode;
-        const uint32_t bmin_r = row_min_u32(pan >> 1);  // oldest scan snapshot for this row's query
+        const RowScreen rs = row_screen(sh.pub[slot_r], row, sub, active, mg);
+        const uint32_t bmin_r = rs.bmin;
         if (__ballot(active && (n0 - bmin_r > 64u || bmin_r > n0)) != 0) { stop = 4; break; }  // ring would have wrapped (bug guard)
-        // nodes committed after that snapshot (at most a few): lanes of the row stride over them
+        const bool clear_r = active && rs.clear;
+        // the screen's winner with its binary64 coordinates and d2 (lane sub == 0 of the row carries it)
+        double cc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) cc[k] = node_coord32<DIM>(sh, tree, cap, st0.n_nodes, n0, k, (clear_r && rs.cand < n0) ? rs.cand : 0u);
+        const bool inS = clear_r && sub == 0;
+        const double pb = inS ? dist2<D>(cc, q, DIM) : __builtin_inf();
+        const uint32_t pidxS = rs.cand;
+        // nodes committed after the oldest snapshot (at most a few): lanes of the row stride over them
         Scan pd{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
         if (active) {
             for (uint32_t i = bmin_r + sub; i < n0; i += 16) {
@@ -374,20 +468,16 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         const uint32_t rowS = (uint32_t)(__ballot(nearS) >> (16 * row)) & 0xFFFFu;
         const uint32_t rowP = (uint32_t)(__ballot(nearP) >> (16 * row)) & 0xFFFFu;
         const bool from_scan = rowS != 0;
-        const uint32_t wsub = from_scan ? (uint32_t)(__ffs((int)rowS) - 1) : (rowP ? (uint32_t)(__ffs((int)rowP) - 1) : 0u);
+        const uint32_t wsub = from_scan ? 0u : (rowP ? (uint32_t)(__ffs((int)rowP) - 1) : 0u);
         const int src_lane = (int)(16 * row + wsub);
-        const uint32_t wS = (uint32_t)__shfl((int)pidxS, src_lane, 64), wP = (uint32_t)__shfl((int)pd.slot, src_lane, 64);
-        const uint32_t nearest_r = from_scan ? wS : wP;
-        // ambiguous iff a second node is near: another near candidate, a near wave that saw a second near node,
-        // or a lane whose second-best recent node is near too
-        const bool amb_l = (nearS && (pidxS != nearest_r || (pan & 1u) != 0)) || (nearP && pd.slot != nearest_r) ||
-                           (active && pd.h2 <= hb);
-        const bool amb_r = ((uint32_t)(__ballot(amb_l) >> (16 * row)) & 0xFFFFu) != 0 || (rowS == 0 && rowP == 0);
+        const uint32_t wP = (uint32_t)__shfl((int)pd.slot, src_lane, 64);
+        const uint32_t nearest_r = from_scan ? pidxS : wP;
+        // ambiguous iff the screen could not name a winner, or a second node is near the binary64 minimum
+        const bool amb_l = (nearP && pd.slot != nearest_r) || (active && pd.h2 <= hb);
+        const bool amb_r = !clear_r || ((uint32_t)(__ballot(amb_l) >> (16 * row)) & 0xFFFFu) != 0 || (rowS == 0 && rowP == 0);
         double q_near[D], qn[D], mid[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k)
-            q_near[k] = from_scan ? node_coord<DIM>(sh, tree, cap, st0.n_nodes, n0, k, active && nearest_r != kNoNode ? nearest_r : 0u)
-                                  : sh.newn[nearest_r & 63][k];
+        for (int k = 0; k < D; ++k) q_near[k] = from_scan ? cc[k] : sh.newn[nearest_r & 63][k];
         steer<DIM>(p, false, g_r, q_near, q, qn);
         lerp<DIM>(q_near, qn, 0.5, mid, DIM);
         bool maybe_l = false;
@@ -401,6 +491,84 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
         }
         const bool maybe_r = extras || (((uint32_t)(__ballot(maybe_l) >> (16 * row)) & 0xFFFFu) != 0);
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_comb += now - t_mark; t_mark = now; }
+
+        // ---- batch commit: when no query of a full batch is ambiguous, no node accepted earlier in the batch comes
+        //      near a later query, the node cap is not reached inside the batch and no goal hit has to stop the launch,
+        //      the four iterations are independent given the row results, and the per-query bookkeeping below (the
+        //      "sequential phase", ~900 cycles per query of scalar code) collapses into one pass.  Anything else falls
+        //      through to the sequential phase, which is the reference's order literally.
+        if (nbq == (uint32_t)kBatch && __ballot(amb_r) == 0) {
+            // motion checks of the rows the midpoint filter could not clear (is_valid is pure: the order is free)
+            uint32_t okmask = (1u << kBatch) - 1u;
+            if (nobs > 0) {
+#pragma unroll
+                for (int r = 0; r < kBatch; ++r) {
+                    if (__builtin_amdgcn_readlane(maybe_r ? 1 : 0, 16 * r) != 0) {
+                        double a[D], bq[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) { a[k] = readlane_f64(q_near[k], 16 * r); bq[k] = readlane_f64(qn[k], 16 * r); }
+                        if (!motion_lanes<DIM>(p, lane, a, bq, oc, othr, ofilt, ns64)) okmask &= ~(1u << r);
+                    }
+                }
+            }
+            const bool ins = !p.freeze;
+            const uint32_t cnt = ins ? (uint32_t)__popc(okmask) : 0u;
+            const bool ok_l = ((okmask >> row) & 1u) != 0;
+            const bool dup_l = g_r == 0.0;
+            bool special = ins && n + cnt >= p.max_nodes;   // a later query of the batch might have to stop at the cap
+            if (ins && !special) {
+                // would a node accepted earlier in the batch be (nearly) as close to this row's query as its nearest?
+                bool conflict_l = false;
+#pragma unroll
+                for (int a = 0; a < kBatch - 1; ++a) {
+                    double ca[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ca[k] = readlane_f64(qn[k], 16 * a);
+                    const bool a_new = ((okmask >> a) & 1u) != 0 && readlane_f64(g_r, 16 * a) != 0.0;   // accepted and not a duplicate
+                    conflict_l = conflict_l || (a_new && row > (uint32_t)a && hi32(dist2<D>(ca, q, DIM)) <= hb);
+                }
+                const bool hit_l = ok_l && dist2<D>(qn, goal_c, DIM) <= goal_thr;
+                const uint64_t hits = __ballot(hit_l && sub == 0);
+                special = __ballot(conflict_l) != 0 || (hits != 0 && p.stop_at_goal);
+                if (!special) {
+                    const uint32_t idx = n + (uint32_t)__popc(okmask & ((1u << row) - 1u));
+                    if (ok_l && sub == 0) {
+                        // 6. insert (rrt.rs:213-217), as in the sequential phase
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            sh.newn[idx & 63][k] = dup_l ? __builtin_inf() : qn[k];
+                            tree[(size_t)k * cap + idx] = qn[k];
+                        }
+                        parent[idx] = (int32_t)nearest_r;
+                        skip[idx] = dup_l ? 1 : 0;
+                    }
+                    if (hits != 0 && st.goal_node < 0)   // 7. goal test (rrt.rs:220-223): the first hit in query order
+                        st.goal_node = (int32_t)__builtin_amdgcn_readlane((int)idx, __ffsll((unsigned long long)hits) - 1);
+                    n += cnt;
+                    if (lane == 0) lds_post(&sh.committed, n);
+                }
+            }
+            if (!special) {
+                uint64_t h = st.checksum;
+#pragma unroll
+                for (int r = 0; r < kBatch; ++r) {
+                    h = fnv_mix(h, (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)nearest_r, 16 * r));
+#pragma unroll
+                    for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(readlane_f64(qn[k], 16 * r))));
+                    h = fnv_mix(h, (uint64_t)((okmask >> r) & 1u));
+                }
+                st.checksum = h;
+                st.iterations += kBatch;
+                st.accepted += (uint64_t)__popc(okmask);
+                draws_done = uni64((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_r, 16 * (kBatch - 1)) |
+                                   ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_r >> 32), 16 * (kBatch - 1)) << 32));
+                if (lane < (uint32_t)kBatch) lds_post(&sh.done[(jr + lane) & (kRing - 1)], 0);   // free the slots ...
+                if (lane == 0) lds_post(&sh.resolved, jr + (uint32_t)kBatch);                     // ... before they are handed out again
+                jr += (uint32_t)kBatch;
+                if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
+                continue;
+            }
+        }
 
         // ---- sequential phase: commit in query order; a node committed earlier in this batch that is
         //      closer (or near-tied) to a later query forces that query through resolve_one
@@ -444,7 +612,6 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                         ok = motion_lanes<DIM>(p, lane, qnr, q_new, oc, othr, ofilt, ns64);
                     }
                 }
-                // bookkeeping (wave-uniform, on the scalar unit where the compiler can)
                 uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
 #pragma unroll
                 for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(q_new[k])));
@@ -505,23 +672,23 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
     }
 }
 
-// instantiations: (dim, slots) -> capacity 512 * slots nodes
-static int pick_slots(uint32_t cap) {
+// instantiations: (dim, slots) -> capacity as in rrt_resident.hip
+static int pick_slots32(uint32_t cap) {
     const uint32_t need = (cap + kScanThreads - 1) / kScanThreads;
     if (need <= 4) return 4;
     if (cap <= Layout<21>::kCapacity) return 21;
     return 0;
 }
 
-bool resident_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && pick_slots(cap) != 0; }
+bool resident32_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && pick_slots32(cap) != 0; }
 
-void launch_rrt_resident(const DevParams& p, hipStream_t stream) {
+void launch_rrt_resident32(const DevParams& p, hipStream_t stream) {
     dim3 grid(p.n_problems), block(kPipeThreads);
-    const int s = pick_slots(p.cap);
-#define OXHIP_LAUNCH(DIM_, S_)                                                                              \
-    do {                                                                                                    \
-        if (p.dbg) hipLaunchKernelGGL((rrt_resident_kernel<DIM_, S_, true>), grid, block, 0, stream, p);    \
-        else hipLaunchKernelGGL((rrt_resident_kernel<DIM_, S_, false>), grid, block, 0, stream, p);         \
+    const int s = pick_slots32(p.cap);
+#define OXHIP_LAUNCH(DIM_, S_)                                                                                \
+    do {                                                                                                      \
+        if (p.dbg) hipLaunchKernelGGL((rrt_resident32_kernel<DIM_, S_, true>), grid, block, 0, stream, p);    \
+        else hipLaunchKernelGGL((rrt_resident32_kernel<DIM_, S_, false>), grid, block, 0, stream, p);         \
     } while (0)
     if (p.dim == 3) {
         if (s == 4) OXHIP_LAUNCH(3, 4); else OXHIP_LAUNCH(3, 21);

@@ -209,6 +209,48 @@ __device__ __forceinline__ bool motion_full(const DevParams& p, uint32_t lane, c
     return __ballot(bad) == 0;
 }
 
+// check_motion (rrt.rs:90-116) for a steered motion (length <= max_distance), lane-parallel over the STEPS: the midpoint
+// filter below first names the spheres the segment can touch at all (usually one or two of 64), then lane s-1 tests
+// interpolated state s against just those -- one pass instead of one pass per step.  is_valid is pure and the filter only
+// ever removes spheres that provably cannot be hit, so the verdict equals the reference's first-invalid early exit.
+// Spheres beyond the first 64 and all boxes are tested against every step, unfiltered.
+template <int DIM>
+__device__ __forceinline__ bool sphere_maybe_hit(const double c[DIM], double filt, const double mid[DIM]);
+template <int DIM>
+__device__ __forceinline__ bool motion_lanes(const DevParams& p, uint32_t lane, const double q_near[DIM], const double q_new[DIM],
+                                             const double oc[DIM], double othr, double ofilt, uint32_t ns64) {
+    const uint32_t nobs = p.n_spheres + p.n_boxes;
+    const double dist = sqrt(dist2<DIM>(q_near, q_new, DIM));
+    const uint32_t nsteps = num_steps_u32(dist, p.res);
+    bool bad = false;
+    if (nsteps <= 1) {
+        bad = !(dist2<DIM>(oc, q_new, DIM) > othr);
+        for (uint32_t j = ns64 + lane; j < nobs; j += 64) bad = bad || obstacle_hit<DIM>(p, DIM, q_new, j);
+        return __ballot(bad) == 0;
+    }
+    double mid[DIM];
+    lerp<DIM>(q_near, q_new, 0.5, mid, DIM);
+    const uint64_t cand = __ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid));
+    const double dn = (double)nsteps;
+    for (uint64_t base = 0; base < nsteps; base += 64) {
+        const uint64_t s = base + lane + 1;
+        const bool act = s <= nsteps;
+        const double t = (double)(uint32_t)(act ? s : 1u) / dn;
+        double x[DIM];
+        lerp<DIM>(q_near, q_new, t, x, DIM);
+        for (uint64_t m = cand; m != 0; m &= m - 1) {
+            const int j = __ffsll((unsigned long long)m) - 1;
+            double c[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) c[k] = readlane_f64(oc[k], j);
+            bad = bad || (act && !(dist2<DIM>(c, x, DIM) > readlane_f64(othr, j)));
+        }
+        for (uint32_t j = ns64; j < nobs; ++j) bad = bad || (act && obstacle_hit<DIM>(p, DIM, x, j));
+        if (__ballot(bad) != 0) break;
+    }
+    return __ballot(bad) == 0;
+}
+
 // Conservative midpoint filter (exactness: DESIGN.md section 3): every interpolated state lies within
 // max_distance/2 of the segment midpoint, so d2(centre, mid) > (r + max_distance/2 + margin)^2 proves
 // a sphere cannot be hit.  The filter never decides a motion invalid; it only skips provably valid work.

@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 from oxmpl_amd import capi, scenarios  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
 
-KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED]
-KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_PRUNED: "pruned"}
+KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED, capi.KERNEL_RESIDENT_F32]
+KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_PRUNED: "pruned",
+         capi.KERNEL_RESIDENT_F32: "resident_f32"}
 
 
 def _batch_or_skip(*args, **kw):
@@ -294,7 +295,7 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
             lo = rng.random((nb, dim)) * 6.0 - 1.0
             sc["boxes"] = (lo, lo + rng.random((nb, dim)) * 0.8 + 0.1)
         P = 6
-        if kernel in (capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED) and dim not in (2, 3):
+        if kernel in (capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED, capi.KERNEL_RESIDENT_F32) and dim not in (2, 3):
             continue  # the resident kernel is instantiated for R^2 / R^3 only
         gpu = _gpu_for(sc, P, 400, False, 7, 100, kernel)
         gpu.solve(500)
