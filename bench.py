@@ -34,6 +34,10 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 # measured on this chip with tools/scan_bench.hip: the bare register scan (10,240 nodes, tie detector
 # included, no reduce / resolve) sustains 1.0 us per CU whatever the wave geometry -> 256 CUs
 VALU_SCAN_CEILING_ITS = 258.0e6
+# the binary32-screen kernel (rrt_resident32.hip): 6 VALU instructions per (register row of 64 nodes, query) -- three packed
+# f32 ops per query pair halved, and_or + med3 + min -- over 160 rows, 4 cycles per wave64 instruction, 4 SIMDs per CU,
+# 2.4 GHz, 256 CUs: an instruction-count bound for the scan alone (no reduce, no resolver)
+VALU_SCREEN_CEILING_ITS = 256 * 4 * 2.4e9 / (160 * 6 * 4)
 
 
 def measured_traffic(kernel_name, iters_per_launch):
@@ -189,12 +193,15 @@ def main():
                        "spheres": 64, "max_distance": 0.5, "goal_bias": 0.05, "parallelism": "problem-parallel x%d" % world,
                        "kernel": kname},
             # bound "hbm" = the roofline of any design that re-reads the tree per iteration (33.3 M it/s);
-            # the resident kernel keeps the tree in VGPRs, so frac > 1 and its own bound is f64 VALU issue
+            # the resident kernels keep the tree in VGPRs, so frac > 1 and their own bound is VALU issue
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kname, iters_per_launch),
                          "kernel_avg_ms": avg_launch_ms, "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER,
-                         "valu": {"bound": "f64-valu scan (tools/scan_bench.hip, measured)", "peak_iterations_per_s": VALU_SCAN_CEILING_ITS,
-                                  "frac": (iters_per_launch / (avg_launch_ms * 1e-3)) / VALU_SCAN_CEILING_ITS}},
+                         "valu": ({"bound": "packed-f32 screen, VALU instruction count (bench.py)", "peak_iterations_per_s": VALU_SCREEN_CEILING_ITS,
+                                   "frac": (iters_per_launch / (avg_launch_ms * 1e-3)) / VALU_SCREEN_CEILING_ITS}
+                                  if kname == "resident_f32" else
+                                  {"bound": "f64-valu scan (tools/scan_bench.hip, measured)", "peak_iterations_per_s": VALU_SCAN_CEILING_ITS,
+                                   "frac": (iters_per_launch / (avg_launch_ms * 1e-3)) / VALU_SCAN_CEILING_ITS})},
             "grow": {"iterations": float(allst[:, 4].sum()), "wall_s": float(allst[:, 5].max()),
                      "iterations_per_s": float(allst[:, 4].sum() / allst[:, 5].max()),
                      "kernel_ms_rank0": float(allst[0, 6])},

@@ -71,7 +71,7 @@ typedef enum oxhip_space_kind {
 } oxhip_space_kind;
 
 typedef enum oxhip_kernel_kind {
-    OXHIP_KERNEL_AUTO = 0,      /* resident when the tree fits the register file, else streaming */
+    OXHIP_KERNEL_AUTO = 0,      /* resident (binary32 screen) when the tree fits the register file, else streaming */
     OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
     OXHIP_KERNEL_RESIDENT = 2,  /* tree held in the workgroup's vector registers, every node scanned */
     OXHIP_KERNEL_PRUNED = 3,    /* resident + spatially sorted rows with bounding boxes: exact pruned scan */

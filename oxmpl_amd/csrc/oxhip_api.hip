@@ -180,7 +180,9 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
 
     uint32_t kind = cfg->kernel;
     if (cfg->planner != OXHIP_PLANNER_RRT) kind = OXHIP_KERNEL_STREAM;
-    if (kind == OXHIP_KERNEL_AUTO) kind = resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
+    if (kind == OXHIP_KERNEL_AUTO)
+        kind = resident32_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT_F32
+             : resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_PRUNED && !pruned_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
         return fail(OXHIP_ERR_BAD_ARG, "resident (pruned) kernel does not support this (dim, max_nodes)");

@@ -12,7 +12,7 @@
 //     and the comparison with the nodes committed after the scan's snapshot are then computed in binary64 from
 //     the binary64 node exactly as in rrt_resident.hip.  When the screen cannot separate winner and runner-up
 //     (~1e-4 of queries) the resolver runs the reference's own loop over the binary64 tree in HBM / L2.
-// The result is bit-identical to the binary64 kernels (and to the oracle); only the work to find it shrinks.
+// The result is bit-identical to the binary64 kernels; only the work to find it shrinks.
 //
 // Error model (u = 2^-24; M = largest coordinate magnitude among the bounds, the goal centre and the tree: every
 // query is a sample inside the bounds or the goal centre, every new node a convex combination of two of those):
@@ -36,6 +36,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr uint32_t kKeyInf = 0x7F80001Fu;   // +inf with slot 31: "no node"
 constexpr uint32_t kSlotMask = 31u;
+#ifndef OXHIP_RING32
+#define OXHIP_RING32 32
+#endif
+constexpr int kRing32 = OXHIP_RING32;        // queries in flight (power of two)
+#ifndef OXHIP_S32
+#define OXHIP_S32 23
+#define OXHIP_C32 11
+#endif
+constexpr int kS32 = OXHIP_S32, kC32 = OXHIP_C32;   // register rows of the heavy / of every scanner wave
 
 struct alignas(16) WavePub32 {   // one wave's screen result for one query (one 16-byte LDS store)
     uint32_t k1;   // smallest key of the wave
@@ -47,9 +56,9 @@ struct alignas(16) WavePub32 {   // one wave's screen result for one query (one 
 template <int DIM>
 struct PipeShared32 {
     uint32_t rng_buf[16][64];
-    QSlot<DIM> qring[kRing];
-    WavePub32 pub[kRing][kScanWaves];
-    uint32_t done[kRing];
+    QSlot<DIM> qring[kRing32];
+    WavePub32 pub[kRing32][kScanWaves];
+    uint32_t done[kRing32];
     double newn[64][DIM];
     double obs[DIM + 1][64];
     uint32_t sampled, resolved, committed, stop_flag;
@@ -65,6 +74,32 @@ __device__ __forceinline__ double node_coord32(const PipeShared32<DIM>& sh, cons
 
 __device__ __forceinline__ uint32_t f32_bits(float v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ float bits_f32(uint32_t v) { return __builtin_bit_cast(float, v); }
+
+// Wave-wide unsigned minima of four independent values, one v_min_u32_dpp per value and step (the compiler's
+// lowering of update_dpp + min costs three VALU instructions per step).  The four chains interleave, so a value's next
+// step is three instructions behind its last write and the VALU-write -> DPP-read hazard (2 wait states) needs no
+// padding; the leading s_nop covers whatever produced the inputs.  Lanes a step gives no source keep their value.
+#define OXHIP_MIN4_STEP(ctrl)                   \
+    "v_min_u32_dpp %0, %0, %0 " ctrl "\n"       \
+    "v_min_u32_dpp %1, %1, %1 " ctrl "\n"       \
+    "v_min_u32_dpp %2, %2, %2 " ctrl "\n"       \
+    "v_min_u32_dpp %3, %3, %3 " ctrl "\n"
+__device__ __forceinline__ void wave_min4_u32(uint32_t (&v)[4]) {
+    uint32_t a = v[0], b = v[1], c = v[2], d = v[3];
+    asm("s_nop 1\n"
+        OXHIP_MIN4_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+        OXHIP_MIN4_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        OXHIP_MIN4_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
+        OXHIP_MIN4_STEP("row_mirror row_mask:0xf bank_mask:0xf")
+        OXHIP_MIN4_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        OXHIP_MIN4_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    v[0] = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+    v[1] = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
+    v[2] = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
+    v[3] = (uint32_t)__builtin_amdgcn_readlane((int)d, 63);
+}
+#undef OXHIP_MIN4_STEP
 
 // per-lane screen state of one query
 struct Screen {
@@ -111,11 +146,11 @@ __device__ __forceinline__ RowScreen row_screen(const WavePub32* pubs, uint32_t 
     return r;
 }
 
-template <int DIM, int S, bool STAMP>
+template <int DIM, int S, int C, bool STAMP>
 __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams p) {
     constexpr int D = DIM;
     static_assert(S <= 32, "the slot number lives in 5 key bits");
-    static_assert(kBatch % 2 == 0, "queries are screened in pairs");
+    static_assert(kBatch == 4, "queries are screened in pairs and reduced four at a time");
     const uint32_t prob = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = uni(tid >> 6), lane = tid & 63;
@@ -131,7 +166,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
     uint8_t* skip = p.skip + (size_t)prob * cap;
     const uint32_t budget = (uint32_t)p.budget;  // the host keeps a launch's budget below 2^31
 
-    if (tid < kRing) sh.done[tid] = 0;
+    if (tid < kRing32) sh.done[tid] = 0;
     if (tid == 0) {
         sh.sampled = 0;
         sh.resolved = 0;
@@ -143,7 +178,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
 
     if (wave < kScanWaves) {
         // ================================================================= scanner waves
-        using Lay = Layout<S>;
+        using Lay = Layout<S, C>;
         uint32_t n_local = st0.n_nodes;
         float tr[DIM][S];
         uint32_t mab = 0;
@@ -168,7 +203,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
         for (uint32_t j = 0; j < budget; j += kBatch) {
             const uint32_t nb = (budget - j < (uint32_t)kBatch) ? (budget - j) : (uint32_t)kBatch;
             const uint32_t need = j + nb;
-            // wait until the pass's queries are sampled (implies their ring slots were consumed kRing queries ago)
+            // wait until the pass's queries are sampled (implies their ring slots were consumed kRing32 queries ago)
             for (uint32_t spins = 0; seen_sampled < need; ++spins) {
                 if (lds_peek(&sh.stop_flag) != 0 || spins > kMaxSpins) break;  // every spin is bounded
                 seen_sampled = uni(lds_peek(&sh.sampled));
@@ -198,7 +233,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
             f32x2 q[kBatch / 2][D];
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
-                const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kRing - 1);
+                const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kRing32 - 1);
 #pragma unroll
                 for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = (float)unid(sh.qring[slot].q[k]);
             }
@@ -209,10 +244,10 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_pre += now - t_mark; t_mark = now; }
             // screen (rrt.rs:187-196 in binary32): groups of kGroup slots under one uniform branch
 #pragma unroll
-            for (int g0 = 0; g0 < S; g0 += group_len<S>(g0)) {
+            for (int g0 = 0; g0 < S; g0 += group_len<S, C>(g0)) {
                 if ((uint32_t)g0 < nslots) {
 #pragma unroll
-                    for (int s = g0; s < g0 + group_len<S>(g0); ++s) {
+                    for (int s = g0; s < g0 + group_len<S, C>(g0); ++s) {
 #pragma unroll
                         for (int bp = 0; bp < kBatch / 2; ++bp) {
                             f32x2 e = (f32x2){tr[0][s], tr[0][s]} - q[bp][0];
@@ -233,17 +268,19 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
             uint32_t k1w[kBatch], k2w[kBatch];
             int wl[kBatch];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) k1w[b] = wave_min_u32(sc[b].b1);
+            for (int b = 0; b < kBatch; ++b) k1w[b] = sc[b].b1;
+            wave_min4_u32(k1w);
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
                 const uint64_t eqm = __ballot(sc[b].b1 == k1w[b]);
                 wl[b] = __ffsll((unsigned long long)eqm) - 1;   // eqm != 0: the minimum is attained
-                k2w[b] = wave_min_u32((int)lane == wl[b] ? sc[b].h2 : sc[b].b1);
+                k2w[b] = (int)lane == wl[b] ? sc[b].h2 : sc[b].b1;
             }
+            wave_min4_u32(k2w);
 #pragma unroll
             for (int b = 0; b < kBatch; ++b) {
                 if ((uint32_t)b < nb) {
-                    const uint32_t slot = (j + (uint32_t)b) & (kRing - 1);
+                    const uint32_t slot = (j + (uint32_t)b) & (kRing32 - 1);
                     if (lane == 0) {
                         WavePub32 out;
                         out.k1 = k1w[b];
@@ -315,7 +352,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
     // ---- one query, the reference's sequential semantics in full (tails, batch conflicts, near-ties):
     //      candidates = the screen's winner + every node committed after the oldest scan snapshot
     auto resolve_one = [&](uint32_t jq, uint32_t& nearest, double (&q_new)[D], bool& dup) -> bool {
-        const uint32_t slot = jq & (kRing - 1);
+        const uint32_t slot = jq & (kRing32 - 1);
         double q[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) q[k] = unid(sh.qring[slot].q[k]);
@@ -392,8 +429,8 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
     while (jr < budget) {
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
         // sample ahead (rrt.rs:177-184); a query may only reuse a ring slot after its previous tenant was resolved
-        if (js < budget && js - jr <= (uint32_t)(kRing / 2)) {
-            uint32_t m = jr + kRing - js;  // free ring slots
+        if (js < budget && js - jr <= (uint32_t)(kRing32 / 2)) {
+            uint32_t m = jr + kRing32 - js;  // free ring slots
             if (m > budget - js) m = budget - js;
             const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + D) + 64;
             if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
@@ -403,11 +440,11 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
 #pragma unroll
                 for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
             }
-            if (!sample_batch<DIM>(rng, p, goal_c, m, lane, sh.qring, js)) {
+            if (!sample_batch<DIM, kRing32>(rng, p, goal_c, m, lane, sh.qring, js)) {
                 for (uint32_t b = 0; b < m; ++b) {  // (never expected) a redraw ran past the window: one by one
                     double qn[D];
                     sample_state<D, false>(rng, p, DIM, goal_c, qn);
-                    QSlot<DIM>& qs = sh.qring[(js + b) & (kRing - 1)];
+                    QSlot<DIM>& qs = sh.qring[(js + b) & (kRing32 - 1)];
                     if (lane == 0) {
 #pragma unroll
                         for (int k = 0; k < D; ++k) qs.q[k] = qn[k];
@@ -424,7 +461,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
         const uint32_t nbq = (budget - jr < (uint32_t)kBatch) ? (budget - jr) : (uint32_t)kBatch;
         uint32_t spins = 0;
         for (uint32_t b = 0; b < nbq; ++b) {
-            while (uni(lds_peek(&sh.done[(jr + b) & (kRing - 1)])) < (uint32_t)kScanWaves && spins <= kMaxSpins) {
+            while (uni(lds_peek(&sh.done[(jr + b) & (kRing32 - 1)])) < (uint32_t)kScanWaves && spins <= kMaxSpins) {
                 __builtin_amdgcn_s_sleep(1);
                 ++spins;
             }
@@ -435,7 +472,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
         // ---- row-parallel phase: DPP row r (16 lanes) works on query jr + r against the tree of n0 nodes
         const uint32_t n0 = n;
         const bool active = row < nbq;
-        const uint32_t slot_r = (jr + (active ? row : 0u)) & (kRing - 1);
+        const uint32_t slot_r = (jr + (active ? row : 0u)) & (kRing32 - 1);
         double q[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) q[k] = sh.qring[slot_r].q[k];
@@ -562,7 +599,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
                 st.accepted += (uint64_t)__popc(okmask);
                 draws_done = uni64((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_r, 16 * (kBatch - 1)) |
                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_r >> 32), 16 * (kBatch - 1)) << 32));
-                if (lane < (uint32_t)kBatch) lds_post(&sh.done[(jr + lane) & (kRing - 1)], 0);   // free the slots ...
+                if (lane < (uint32_t)kBatch) lds_post(&sh.done[(jr + lane) & (kRing32 - 1)], 0);   // free the slots ...
                 if (lane == 0) lds_post(&sh.resolved, jr + (uint32_t)kBatch);                     // ... before they are handed out again
                 jr += (uint32_t)kBatch;
                 if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
@@ -585,7 +622,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
             }
             if (!leave && (uint32_t)b < nbq) {
                 const int l0 = 16 * b;
-                const uint32_t slot = (jr + (uint32_t)b) & (kRing - 1);
+                const uint32_t slot = (jr + (uint32_t)b) & (kRing32 - 1);
                 const double g_b = readlane_f64(g_r, l0);
                 double q_b[D];
 #pragma unroll
@@ -676,7 +713,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
 static int pick_slots32(uint32_t cap) {
     const uint32_t need = (cap + kScanThreads - 1) / kScanThreads;
     if (need <= 4) return 4;
-    if (cap <= Layout<21>::kCapacity) return 21;
+    if (cap <= Layout<kS32, kC32>::kCapacity) return kS32;
     return 0;
 }
 
@@ -685,15 +722,15 @@ bool resident32_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim 
 void launch_rrt_resident32(const DevParams& p, hipStream_t stream) {
     dim3 grid(p.n_problems), block(kPipeThreads);
     const int s = pick_slots32(p.cap);
-#define OXHIP_LAUNCH(DIM_, S_)                                                                                \
+#define OXHIP_LAUNCH(DIM_, S_, C_)                                                                               \
     do {                                                                                                      \
-        if (p.dbg) hipLaunchKernelGGL((rrt_resident32_kernel<DIM_, S_, true>), grid, block, 0, stream, p);    \
-        else hipLaunchKernelGGL((rrt_resident32_kernel<DIM_, S_, false>), grid, block, 0, stream, p);         \
+        if (p.dbg) hipLaunchKernelGGL((rrt_resident32_kernel<DIM_, S_, C_, true>), grid, block, 0, stream, p);    \
+        else hipLaunchKernelGGL((rrt_resident32_kernel<DIM_, S_, C_, false>), grid, block, 0, stream, p);         \
     } while (0)
     if (p.dim == 3) {
-        if (s == 4) OXHIP_LAUNCH(3, 4); else OXHIP_LAUNCH(3, 21);
+        if (s == 4) OXHIP_LAUNCH(3, 4, 4); else OXHIP_LAUNCH(3, kS32, kC32);
     } else {
-        if (s == 4) OXHIP_LAUNCH(2, 4); else OXHIP_LAUNCH(2, 21);
+        if (s == 4) OXHIP_LAUNCH(2, 4, 4); else OXHIP_LAUNCH(2, kS32, kC32);
     }
 #undef OXHIP_LAUNCH
 }

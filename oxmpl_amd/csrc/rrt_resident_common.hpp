@@ -87,12 +87,13 @@ __device__ __forceinline__ void store_slot(const double (&tr)[DIM][S], uint32_t 
 // ~20 % slower than the other six.  The S = 21 layout therefore gives them 17 slots and the other
 // six waves 21: rows 0..16 span all 512 threads, rows 17..20 only the 384 threads of waves
 // 1,2,3,5,6,7 (17*512 + 4*384 = 10,240 nodes).  Smaller instantiations use the plain even layout.
-template <int S>
+// (C = rows every wave holds; the binary32 kernel, whose scans are cheaper relative to the resolver's work, uses 23 / 11.)
+template <int S, int C = (S == 21 ? 17 : S)>
 struct Layout {
-    static constexpr bool kUneven = (S == 21);
-    static constexpr uint32_t kCommon = kUneven ? 17u : (uint32_t)S;   // rows every wave holds
+    static constexpr bool kUneven = (C != S);
+    static constexpr uint32_t kCommon = (uint32_t)C;   // rows every wave holds
     static constexpr uint32_t kHeavyThreads = 384;
-    static constexpr uint32_t kCapacity = kUneven ? (17u * 512u + 4u * 384u) : (uint32_t)S * 512u;
+    static constexpr uint32_t kCapacity = (uint32_t)C * 512u + (uint32_t)(S - C) * kHeavyThreads;
     __device__ static __forceinline__ bool heavy(uint32_t wave) { return !kUneven || (wave & 3u) != 0; }
     __device__ static __forceinline__ uint32_t node_index(uint32_t wave, uint32_t lane, uint32_t slot) {
         if (slot < kCommon) return slot * 512u + wave * 64u + lane;
@@ -283,7 +284,7 @@ __device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {
 // round per goal sample in the batch).  A rejected range draw (res >= hi, probability ~2^-53) or a
 // read past the LDS word window makes the function return false with nothing written; the caller
 // then samples that batch sequentially.
-template <int DIM>
+template <int DIM, int RING = kRing>
 __device__ __forceinline__ bool sample_batch(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m,
                                              uint32_t lane, QSlot<DIM>* qring, uint32_t js) {
     const uint64_t win_lo = rng.base_blk * 8;
@@ -322,7 +323,7 @@ __device__ __forceinline__ bool sample_batch(RngWindow& rng, const DevParams& p,
     if (__ballot(act && !goal && redraw) != 0) return false;
     const uint32_t cnt = always_goal ? 0u : (goal ? 1u : 1u + (uint32_t)DIM);
     if (act) {
-        QSlot<DIM>& qs = qring[(js + lane) & (kRing - 1)];
+        QSlot<DIM>& qs = qring[(js + lane) & (RING - 1)];
 #pragma unroll
         for (int k = 0; k < DIM; ++k) qs.q[k] = q[k];
         qs.pos_after = pos0 + off + cnt;
@@ -332,9 +333,9 @@ __device__ __forceinline__ bool sample_batch(RngWindow& rng, const DevParams& p,
 }
 
 // scan groups: kGroup slots per uniform branch, never straddling the common / heavy-only boundary
-template <int S>
+template <int S, int C = (S == 21 ? 17 : S)>
 __host__ __device__ constexpr int group_len(int g0) {
-    const int common = (int)Layout<S>::kCommon;
+    const int common = C;
     int len = kGroup;
     if (g0 < common && g0 + len > common) len = common - g0;
     if (g0 + len > S) len = S - g0;

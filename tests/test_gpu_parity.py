@@ -443,6 +443,37 @@ def test_planner_near_ties_take_the_exact_path(kernel):
     gpu.close()
 
 
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+@pytest.mark.parametrize("scale,offset,max_nodes", [(1.0, 1.0e3, 600), (1.0, 1.0e6, 600), (1.0, -5.0e4, 3000),
+                                                    (1.0e-12, 0.0, 600), (1.0e18, 0.0, 600), (1.0e30, 0.0, 3000),
+                                                    (1.0e100, 0.0, 600)])
+def test_rrt_translated_and_scaled_spaces(kernel, scale, offset, max_nodes):
+    """The same scene moved far from the origin or blown up / shrunk by many orders of magnitude.  For the
+    binary32-screen kernel these are the regimes of its error model: a large offset makes binary32 too coarse to
+    separate any two nodes (every query takes the exact binary64 path), 1e18 and beyond exceed the range in which
+    binary32 squares are trusted at all (1e30: they overflow), 1e-12 exercises the subnormal end.  Results must not
+    move by a bit in any of them, for any kernel."""
+    base = scenarios.config2()
+    t = lambda v: (np.asarray(v, dtype=np.float64) * scale + offset)
+    c, r = base["spheres"]
+    sc = dict(dim=3, bounds=[(float(t(lo)), float(t(hi))) for lo, hi in base["bounds"]],
+              max_distance=base["max_distance"] * scale, goal_bias=0.1, lvs_fraction=base["lvs_fraction"],
+              start=list(t(base["start"])), goal_centre=list(t(base["goal_centre"])), goal_radius=base["goal_radius"] * scale,
+              spheres=(t(c), np.asarray(r) * scale), boxes=None)
+    P, iters = 4, 700
+    gpu = _gpu_for(sc, P, max_nodes, False, 31, 40, kernel)
+    gpu.solve(iters)
+    planners = [_oracle_for(sc, 31, 40 + p, max_nodes, False) for p in range(P)]
+    orc.solve_many(planners, iters, threads=4)
+    for p in range(P):
+        _assert_same_problem(gpu, p, planners[p])
+        gs, gp = gpu.tree(p)
+        os_, op = planners[p].tree()
+        assert np.array_equal(gp, op) and np.array_equal(gs.view(np.uint64), os_.view(np.uint64))
+    assert min(o.num_nodes for o in planners) > 100   # the scene still lets the trees grow
+    gpu.close()
+
+
 def test_solve_before_setup_is_planner_uninitialised():
     b = capi.RRTBatch(2, [(0.0, 1.0)] * 2, 0.1, 0.0, 1, 10)
     with pytest.raises(capi.OxhipError) as ei:

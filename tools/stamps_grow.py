@@ -8,7 +8,7 @@ from oxmpl_amd import capi, scenarios  # noqa: E402
 
 sc = scenarios.config2()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-gpu = scenarios.make_batch(sc, P, 10000, False, 42, 0, 0, capi.KERNEL_RESIDENT)
+gpu = scenarios.make_batch(sc, P, 10000, False, 42, 0, 0, int(sys.argv[3]) if len(sys.argv) > 3 else capi.KERNEL_RESIDENT)
 gpu.enable_stamps(True)
 for target in (2000, 4000, 6000):
     gpu.solve(target)
