@@ -1,7 +1,8 @@
 // rrt_resident32.hip -- the register-resident RRT grow kernel with a binary32 SCREEN in the scanners.
 //
 // Same pipeline as rrt_resident.hip (8 scanner waves + 1 resolver wave per problem, LDS query ring, no
-// workgroup barrier in steady state).  The difference is what the scanner waves hold and compute:
+// workgroup barrier in steady state) plus a tenth wave that only draws the queries (640 threads).  The main
+// difference is what the scanner waves hold and compute:
 //   * the tree sits in VGPRs as binary32 roundings of the binary64 nodes (63 VGPRs for 10,240 nodes in R^3
 //     instead of 126), and the O(n) scan of rrt.rs:187-196 runs in packed binary32 (v_pk_add/mul/fma_f32: two
 //     queries per instruction) with the slot number folded into the low 5 bits of the squared distance, so the
@@ -41,9 +42,10 @@ constexpr uint32_t kSlotMask = 31u;
 #endif
 constexpr int kRing32 = OXHIP_RING32;        // queries in flight (power of two)
 #ifndef OXHIP_S32
-#define OXHIP_S32 23
-#define OXHIP_C32 11
+#define OXHIP_S32 22
+#define OXHIP_C32 14
 #endif
+constexpr int kPipeThreads32 = kScanThreads + 128;   // + the resolver wave + the sampler wave
 constexpr int kS32 = OXHIP_S32, kC32 = OXHIP_C32;   // register rows of the heavy / of every scanner wave
 
 struct alignas(16) WavePub32 {   // one wave's screen result for one query (one 16-byte LDS store)
@@ -54,9 +56,16 @@ struct alignas(16) WavePub32 {   // one wave's screen result for one query (one 
 };
 
 template <int DIM>
+struct alignas(16) QSlot32 {
+    double q[DIM];
+    uint64_t pos_after;  // stream position after this query's draws
+    float qf[4];         // fl32(q): what the scanners screen with (one 16-byte LDS read)
+};
+
+template <int DIM>
 struct PipeShared32 {
     uint32_t rng_buf[16][64];
-    QSlot<DIM> qring[kRing32];
+    QSlot32<DIM> qring[kRing32];
     WavePub32 pub[kRing32][kScanWaves];
     uint32_t done[kRing32];
     double newn[64][DIM];
@@ -147,7 +156,7 @@ __device__ __forceinline__ RowScreen row_screen(const WavePub32* pubs, uint32_t 
 }
 
 template <int DIM, int S, int C, bool STAMP>
-__global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams p) {
+__global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParams p) {
     constexpr int D = DIM;
     static_assert(S <= 32, "the slot number lives in 5 key bits");
     static_assert(kBatch == 4, "queries are screened in pairs and reduced four at a time");
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
             for (int b = 0; b < kBatch; ++b) {
                 const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kRing32 - 1);
 #pragma unroll
-                for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = (float)unid(sh.qring[slot].q[k]);
+                for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = sh.qring[slot].qf[k];   // same value in every lane
             }
             const uint32_t nslots = Lay::slots_in_use(wave, nc);
             Screen sc[kBatch];
@@ -302,6 +311,66 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
         return;
     }
 
+    if (wave == (uint32_t)kScanWaves + 1u) {
+        // ================================================================= sampler wave
+        // rrt.rs:177-184 for the whole launch, ahead of everybody: the queries depend on the RNG stream only, never on
+        // the tree, so they are drawn by a wave of their own and the resolver's critical path starts at the scan results.
+        // A ring slot is reused only after its previous tenant was resolved (`resolved`, posted by the resolver).
+        double goal_c[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
+        __syncthreads();  // the launch's second barrier (see the scanners)
+        RngWindow rng;
+        rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st0.draws);
+        uint64_t t_busy = 0;
+        uint32_t js = 0;
+        while (js < budget) {
+            uint32_t jr_seen = 0;
+            bool go = false;
+            for (uint32_t spins = 0; spins <= kMaxSpins; ++spins) {   // every spin is bounded
+                if (lds_peek(&sh.stop_flag) != 0) break;
+                jr_seen = uni(lds_peek(&sh.resolved));
+                if (js - jr_seen <= (uint32_t)(kRing32 / 2)) { go = true; break; }   // half the ring is free: refill it
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (!go) break;  // stop requested (or a protocol bug: the resolver's own guard reports it)
+            const uint64_t t0 = STAMP ? (uint64_t)clock64() : 0;
+            uint32_t m = jr_seen + kRing32 - js;  // free ring slots
+            if (m > budget - js) m = budget - js;
+            // keep the batch's words inside the LDS window: refill (64 blocks from the current position) when short
+            const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + D) + 64;
+            if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
+                rng.base_blk = uni64(rng.pos >> 3);
+                uint32_t o[16];
+                chacha12_block(rng.seed, rng.base_blk + lane, rng.stream, o);
+#pragma unroll
+                for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
+            }
+            if (!sample_batch<DIM, kRing32, QSlot32<DIM>>(rng, p, goal_c, m, lane, sh.qring, js)) {
+                for (uint32_t b = 0; b < m; ++b) {  // (never expected) a redraw ran past the window: one by one
+                    double qn[D];
+                    sample_state<D, false>(rng, p, DIM, goal_c, qn);
+                    QSlot32<DIM>& qs = sh.qring[(js + b) & (kRing32 - 1)];
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) qs.q[k] = qn[k];
+                        qs.pos_after = rng.pos;
+                    }
+                }
+            }
+            if (lane < m) {   // the binary32 copies the scanners read (LDS is in order within this wave)
+                QSlot32<DIM>& qs = sh.qring[(js + lane) & (kRing32 - 1)];
+#pragma unroll
+                for (int k = 0; k < D; ++k) qs.qf[k] = (float)qs.q[k];
+            }
+            js += m;
+            if (lane == 0) lds_post(&sh.sampled, js);
+            if (STAMP) t_busy += (uint64_t)clock64() - t0;
+        }
+        if (STAMP && p.dbg && prob == 0 && lane == 0) p.dbg[0] = t_busy;
+        return;
+    }
+
     // ===================================================================== resolver wave
     __builtin_amdgcn_s_setprio(3);  // the youngest wave of its SIMD would otherwise queue behind two scanners
     ProblemState st = st0;
@@ -321,14 +390,12 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
     for (int k = 0; k < D; ++k) sh.obs[k][lane] = oc[k];
     sh.obs[D][lane] = ofilt;
 
-    RngWindow rng;
-    rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
     uint64_t draws_done = st.draws;
     uint32_t n = st.n_nodes;
-    uint32_t js = 0, jr = 0;
+    uint32_t jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
     const uint32_t row = lane >> 4, sub = lane & 15;
-    uint64_t t_wait = 0, t_work = 0, t_samp = 0, t_comb = 0, n_amb = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
+    uint64_t t_wait = 0, t_work = 0, t_comb = 0, n_amb = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
     Margins mg;
@@ -428,34 +495,6 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
 
     while (jr < budget) {
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
-        // sample ahead (rrt.rs:177-184); a query may only reuse a ring slot after its previous tenant was resolved
-        if (js < budget && js - jr <= (uint32_t)(kRing32 / 2)) {
-            uint32_t m = jr + kRing32 - js;  // free ring slots
-            if (m > budget - js) m = budget - js;
-            const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + D) + 64;
-            if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
-                rng.base_blk = uni64(rng.pos >> 3);
-                uint32_t o[16];
-                chacha12_block(rng.seed, rng.base_blk + lane, rng.stream, o);
-#pragma unroll
-                for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
-            }
-            if (!sample_batch<DIM, kRing32>(rng, p, goal_c, m, lane, sh.qring, js)) {
-                for (uint32_t b = 0; b < m; ++b) {  // (never expected) a redraw ran past the window: one by one
-                    double qn[D];
-                    sample_state<D, false>(rng, p, DIM, goal_c, qn);
-                    QSlot<DIM>& qs = sh.qring[(js + b) & (kRing32 - 1)];
-                    if (lane == 0) {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) qs.q[k] = qn[k];
-                        qs.pos_after = rng.pos;
-                    }
-                }
-            }
-            js += m;
-            if (lane == 0) lds_post(&sh.sampled, js);
-        }
-        if (STAMP) { uint64_t now = (uint64_t)clock64(); t_samp += now - t_mark; t_mark = now; }
 
         // the scanners publish kBatch queries per pass: resolve them as one batch
         const uint32_t nbq = (budget - jr < (uint32_t)kBatch) ? (budget - jr) : (uint32_t)kBatch;
@@ -704,7 +743,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident32_kernel(DevParams 
         st.stop_reason = stop;
         p.state[prob] = st;
         if (STAMP && p.dbg && prob == 0) {
-            p.dbg[0] = t_samp; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_comb; p.dbg[4] = n_amb; p.dbg[7] = st.iterations;
+            p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_comb; p.dbg[4] = n_amb; p.dbg[7] = st.iterations;
         }
     }
 }
@@ -720,7 +759,7 @@ static int pick_slots32(uint32_t cap) {
 bool resident32_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && pick_slots32(cap) != 0; }
 
 void launch_rrt_resident32(const DevParams& p, hipStream_t stream) {
-    dim3 grid(p.n_problems), block(kPipeThreads);
+    dim3 grid(p.n_problems), block(kPipeThreads32);
     const int s = pick_slots32(p.cap);
 #define OXHIP_LAUNCH(DIM_, S_, C_)                                                                               \
     do {                                                                                                      \

@@ -87,7 +87,7 @@ __device__ __forceinline__ void store_slot(const double (&tr)[DIM][S], uint32_t 
 // ~20 % slower than the other six.  The S = 21 layout therefore gives them 17 slots and the other
 // six waves 21: rows 0..16 span all 512 threads, rows 17..20 only the 384 threads of waves
 // 1,2,3,5,6,7 (17*512 + 4*384 = 10,240 nodes).  Smaller instantiations use the plain even layout.
-// (C = rows every wave holds; the binary32 kernel, whose scans are cheaper relative to the resolver's work, uses 23 / 11.)
+// (C = rows every wave holds; the binary32 kernel, whose scans are cheaper relative to the resolver's work, uses 22 / 14.)
 template <int S, int C = (S == 21 ? 17 : S)>
 struct Layout {
     static constexpr bool kUneven = (C != S);
@@ -284,9 +284,9 @@ __device__ __forceinline__ uint32_t row_min_u32(uint32_t v) {
 // round per goal sample in the batch).  A rejected range draw (res >= hi, probability ~2^-53) or a
 // read past the LDS word window makes the function return false with nothing written; the caller
 // then samples that batch sequentially.
-template <int DIM, int RING = kRing>
+template <int DIM, int RING = kRing, class QS = QSlot<DIM>>
 __device__ __forceinline__ bool sample_batch(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m,
-                                             uint32_t lane, QSlot<DIM>* qring, uint32_t js) {
+                                             uint32_t lane, QS* qring, uint32_t js) {
     const uint64_t win_lo = rng.base_blk * 8;
     const uint64_t pos0 = rng.pos;
     if (pos0 < win_lo || pos0 + (uint64_t)m * (1 + DIM) > win_lo + 512) return false;
@@ -323,7 +323,7 @@ __device__ __forceinline__ bool sample_batch(RngWindow& rng, const DevParams& p,
     if (__ballot(act && !goal && redraw) != 0) return false;
     const uint32_t cnt = always_goal ? 0u : (goal ? 1u : 1u + (uint32_t)DIM);
     if (act) {
-        QSlot<DIM>& qs = qring[(js + lane) & (RING - 1)];
+        QS& qs = qring[(js + lane) & (RING - 1)];
 #pragma unroll
         for (int k = 0; k < DIM; ++k) qs.q[k] = q[k];
         qs.pos_after = pos0 + off + cnt;
