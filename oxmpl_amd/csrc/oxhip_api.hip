@@ -33,6 +33,8 @@ struct oxhip_rrt_batch {
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
+    DevBuf<float> tree32;           // stream / RRT* kernels: fl32 shadow of the tree
+    DevBuf<uint32_t> shadow_state;  // [P][2]
     DevBuf<uint32_t> nb_idx;
     DevBuf<int32_t> parent;
     DevBuf<int32_t> parent_b;
@@ -196,6 +198,19 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_BAD_ARG, "resident kernel does not support this (dim, max_nodes)");
     }
     b->kernel_kind = kind;
+    if ((cfg->planner == OXHIP_PLANNER_RRT && kind == OXHIP_KERNEL_STREAM) || cfg->planner == OXHIP_PLANNER_RRT_STAR) {
+        // the streaming kernels screen their scans over an fl32 shadow of the tree, which they maintain themselves
+        hipError_t e2 = b->tree32.alloc((size_t)P * dim * cap);
+        if (e2 == hipSuccess) e2 = b->shadow_state.alloc((size_t)P * 2);
+        if (e2 == hipSuccess) e2 = hipMemset(b->shadow_state.p, 0, (size_t)P * 2 * sizeof(uint32_t));
+        if (e2 != hipSuccess) {
+            std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e2);
+            oxhip_rrt_batch_destroy(b);
+            return fail(OXHIP_ERR_HIP, msg);
+        }
+        dp.tree32 = b->tree32.p;
+        dp.shadow_state = b->shadow_state.p;
+    }
     *out = b;
     return OXHIP_OK;
 }
@@ -301,6 +316,7 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
     HIP_TRY(hipMemcpy2DAsync(b->tree.p, (size_t)cap * sizeof(double), starts, sizeof(double), sizeof(double),
                              (size_t)P * dim, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemsetAsync(b->skip.p, 0, (size_t)P * cap, b->stream));
+    if (b->shadow_state.p) HIP_TRY(hipMemsetAsync(b->shadow_state.p, 0, (size_t)P * 2 * sizeof(uint32_t), b->stream));  // shadows start over
     std::vector<int32_t> minus1(P, -1);
     HIP_TRY(hipMemcpy2DAsync(b->parent.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
                              sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
@@ -391,6 +407,8 @@ int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const dou
                              (size_t)n * sizeof(double), (size_t)n * sizeof(double), dim, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->parent.p + (size_t)problem * cap, parents_in, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->skip.p + (size_t)problem * cap, skip.data(), n, hipMemcpyHostToDevice, b->stream));
+    if (b->shadow_state.p)   // this problem's fl32 shadow starts over
+        HIP_TRY(hipMemsetAsync(b->shadow_state.p + 2 * (size_t)problem, 0, 2 * sizeof(uint32_t), b->stream));
     std::vector<ProblemState> states;
     if ((st = read_states(b, states)) != OXHIP_OK) return st;
     states[problem].n_nodes = n;

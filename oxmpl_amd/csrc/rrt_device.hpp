@@ -75,6 +75,9 @@ struct DevParams {
     // PRM only (prm_kernels.hip): the midpoint filter's inputs for motions of any length
     const double* sph_r;    // [n_spheres] radii as given
     double filt_abs;        // 1e-9 * largest coordinate magnitude in play (absolute rounding margin)
+    // binary32 screen of the streaming kernels (rrt_stream.hip, rrt_star.hip): fl32 shadow of the tree
+    float* tree32;          // [P][dim][cap] fl32(tree), same layout; maintained by the kernels that insert
+    uint32_t* shadow_state; // [P][2]: nodes whose shadow is valid; bits of the largest |fl32(coordinate)| among them
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -375,6 +378,96 @@ __device__ __forceinline__ bool motion_invalid_wg(const DevParams& p, int dim, c
         for (uint32_t j = lane; j < nobs; j += 64) bad = bad || obstacle_hit<D>(p, dim, s, j);
     }
     return bad;
+}
+
+// ---------------------------------------------------------------- binary32 screen (error model: rrt_resident32.hip)
+// A node whose binary32 squared distance (computed from fl32 inputs) is v lies at true distance
+//   sqrt(v)(1 - R) - A <= d <= sqrt(v)(1 + R) + A,  A = sqrt(D) 4.1 u M + 1e-18,  R = 2^-19 + (D + 2) u,  u = 2^-24,
+// M = largest coordinate magnitude in play.  The kernels use 2A and 2R: a screen winner is accepted only when the
+// runner-up's lower bound exceeds its upper bound; the result is then computed in binary64 from the binary64 node.
+struct ScreenMargins {
+    double a2, r_lo, r_hi;
+    bool usable;   // M small enough for binary32 squares
+};
+__device__ __forceinline__ ScreenMargins screen_margins(double m_all, int dim) {
+    ScreenMargins mg;
+    const double m = m_all * 1.001;   // interpolation rounding over any chain of inserts
+    const double u = 0x1p-24;
+    mg.usable = m < 1e15;             // also false for NaN / inf
+    mg.a2 = 2.0 * (sqrt((double)dim) * 4.1 * u * m + 1e-18);
+    const double r2 = 2.0 * (0x1p-19 + (double)(dim + 2) * u);
+    mg.r_lo = 1.0 - r2;
+    mg.r_hi = 1.0 + r2;
+    return mg;
+}
+// v1 <= v2: smallest and second smallest screened squared distance (binary32 values held in doubles)
+__device__ __forceinline__ bool screen_clear(const ScreenMargins& mg, double v1, double v2) {
+    return mg.usable && (sqrt(v2) * mg.r_lo - mg.a2 > sqrt(v1) * mg.r_hi + mg.a2);   // +inf / NaN first: false
+}
+// largest binary32 squared distance a node within true distance r can show (for threshold screens); +inf when unusable
+__device__ __forceinline__ float screen_threshold(const ScreenMargins& mg, double r) {
+    if (!mg.usable || !(r < 1e18)) return __builtin_inff();
+    const double d = (r * (1.0 + 1e-12) + mg.a2) * mg.r_hi * mg.r_hi;
+    const float t = (float)(d * d * (1.0 + 0x1p-20));
+    return t;
+}
+
+// One thread's share of a screen over the shadow: four consecutive nodes per 16-byte load and coordinate (the SoA rows
+// are 16-byte aligned: cap is a multiple of 1024), `visit(i, s)` for every node i < n with its binary32 squared
+// distance s to qf.  Loads may run up to 3 nodes past n (inside the row: cap >= n rounded up); those are not visited.
+typedef float oxhip_f32x4 __attribute__((ext_vector_type(4)));
+template <int D, class F>
+__device__ __forceinline__ void screen_scan(const float* tree32, size_t cap, uint32_t n, int dim, const float qf[D],
+                                            uint32_t tid, uint32_t nthreads, F&& visit) {
+    for (uint32_t i0 = 4u * tid; i0 < n; i0 += 4u * nthreads) {
+        oxhip_f32x4 e = *reinterpret_cast<const oxhip_f32x4*>(tree32 + i0) - qf[0];
+        oxhip_f32x4 s = e * e;
+#pragma unroll
+        for (int k = 1; k < D; ++k) {
+            if (k < dim) {
+                e = *reinterpret_cast<const oxhip_f32x4*>(tree32 + (size_t)k * cap + i0) - qf[k];
+                s = __builtin_elementwise_fma(e, e, s);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (i0 + (uint32_t)t < n) visit(i0 + (uint32_t)t, s[t]);
+    }
+}
+
+// Brings the fl32 shadow of one problem's tree up to date (nodes [valid, n)) and returns the magnitude bound M for this
+// launch: the shadowed nodes, the bounds and the goal centre.  Whole workgroup; contains barriers.
+template <int D>
+__device__ __forceinline__ double shadow_sync(const DevParams& p, int dim, uint32_t prob, const double* tree, float* tree32,
+                                              size_t cap, uint32_t n, const double* goal_c, uint32_t* lds_word, uint32_t tid,
+                                              uint32_t nthreads) {
+    uint32_t* sst = p.shadow_state + 2 * (size_t)prob;
+    const uint32_t valid = sst[0] <= n ? sst[0] : 0u;
+    if (tid == 0) *lds_word = valid ? sst[1] : 0u;
+    __syncthreads();
+    uint32_t mab = 0;
+    for (uint32_t i = valid + tid; i < n; i += nthreads) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (k < dim) {
+                const float f = (float)tree[(size_t)k * cap + i];
+                tree32[(size_t)k * cap + i] = f;
+                const uint32_t ab = __builtin_bit_cast(uint32_t, f) & 0x7FFFFFFFu;
+                mab = ab > mab ? ab : mab;
+            }
+        }
+    }
+    __hip_atomic_fetch_max(lds_word, mab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();   // shadow writes of this workgroup are visible to it; the maximum is final
+    double m = (double)__builtin_bit_cast(float, *lds_word) * (1.0 + 0x1p-23);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if (k < dim) {
+            m = fmax(m, fmax(fabs(p.lo[k]), fabs(p.hi[k])));
+            m = fmax(m, fabs(goal_c[k]));
+        }
+    }
+    return m;
 }
 
 // ---------------------------------------------------------------- nearest-neighbour reduction

@@ -25,6 +25,7 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
     __shared__ uint32_t rng_buf[16][64];
     __shared__ Best wave_best[kStreamWaves];
     __shared__ Exact wave_exact[kStreamWaves];
+    __shared__ uint32_t shadow_word;
 
     ProblemState st = p.state[prob];
     if (p.stop_at_goal && st.goal_node >= 0) return;  // already solved: solve() is idempotent
@@ -41,6 +42,10 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
     rng.init(rng_buf, p.seed, p.first_problem_id + prob, st.draws);
 
     uint32_t n = st.n_nodes;
+    // binary32 shadow of the tree (half the bytes per scan) and the error bounds of screening with it
+    float* tree32 = p.tree32 + (size_t)prob * p.dim * cap;
+    const ScreenMargins mg = screen_margins(shadow_sync<D>(p, dim, prob, tree, tree32, cap, n, goal_c, &shadow_word, tid, kStreamThreads), dim);
+
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
     for (uint64_t it = 0; it < p.budget; ++it) {
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
@@ -49,8 +54,44 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
         double q[D];
         sample_state<D>(rng, p, dim, goal_c, q);
 
-        // 3. nearest neighbour (rrt.rs:187-196): coalesced SoA scan, d2 compare
+        // 3. nearest neighbour (rrt.rs:187-196).  First a binary32 SCREEN over the shadow (coalesced SoA scan, 4 bytes
+        //    per coordinate): smallest and second smallest squared distance.  If the runner-up is provably farther than
+        //    the winner (screen_clear), the winner is the reference's nearest node and its distance is recomputed in
+        //    binary64 from the binary64 node; otherwise the binary64 scan below decides as before.
         Best best = best_init();
+        bool screened = false;
+        if (mg.usable) {
+            float qf[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k < dim) qf[k] = (float)q[k];
+            float s1 = __builtin_inff(), s2 = __builtin_inff();
+            uint32_t si = 0xFFFFFFFFu;
+            screen_scan<D>(tree32, cap, n, dim, qf, tid, kStreamThreads, [&](uint32_t i, float s) {
+                s2 = __builtin_amdgcn_fmed3f(s, s1, s2);
+                const bool lt = s < s1;
+                s1 = lt ? s : s1;
+                si = lt ? i : si;
+            });
+            best = best_wave_reduce(Best{(double)s1, (double)s2, si});
+            if (lane == 0) wave_best[wave] = best;
+            __syncthreads();
+            best = wave_best[0];
+#pragma unroll
+            for (int w = 1; w < kStreamWaves; ++w) best = best_combine(best, wave_best[w]);
+            screened = screen_clear(mg, best.b1, best.b2);
+            if (!screened) __syncthreads();   // wave_best is reused by the binary64 scan
+        }
+
+        uint32_t nearest;
+        double min_dist;
+        if (screened) {
+            nearest = best.i1;
+            double c[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree[(size_t)k * cap + nearest];
+            min_dist = sqrt(dist2<D>(c, q, dim));
+        } else {
+        best = best_init();
         for (uint32_t i = tid; i < n; i += kStreamThreads) {
             double c[D];
 #pragma unroll
@@ -64,8 +105,6 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
 #pragma unroll
         for (int w = 1; w < kStreamWaves; ++w) best = best_combine(best, wave_best[w]);
 
-        uint32_t nearest;
-        double min_dist;
         if (best_ambiguous(best)) {
             // rare: two d2 within 3 ulps -> exact post-sqrt compare with lowest-index ties
             Exact e{__builtin_inf(), 0xFFFFFFFFu};
@@ -87,6 +126,7 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
         } else {
             nearest = best.i1;
             min_dist = sqrt(best.b1);
+        }
         }
         nearest = uni(nearest);
 
@@ -121,7 +161,12 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
                 // 6. insert (rrt.rs:213-217)
                 if (tid == 0) {
 #pragma unroll
-                    for (int k = 0; k < D; ++k) if (k < dim) tree[(size_t)k * cap + n] = q_new[k];
+                    for (int k = 0; k < D; ++k) {
+                        if (k < dim) {
+                            tree[(size_t)k * cap + n] = q_new[k];
+                            tree32[(size_t)k * cap + n] = (float)q_new[k];
+                        }
+                    }
                     parent[n] = (int32_t)nearest;
                 }
                 ++n;
@@ -141,6 +186,8 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
         st.draws = rng.pos;
         st.stop_reason = stop;
         p.state[prob] = st;
+        p.shadow_state[2 * (size_t)prob] = n;                  // every node up to n has its shadow
+        p.shadow_state[2 * (size_t)prob + 1] = shadow_word;    // (inserts stay inside the hull the bound M covers)
     }
 }
 
