@@ -435,6 +435,28 @@ __device__ __forceinline__ void screen_scan(const float* tree32, size_t cap, uin
     }
 }
 
+// The same for a radius screen: `visit(i)` for every node i < n whose binary32 squared distance is <= thr (one call
+// site of `visit`, reached through a loop over the hits of a load: the candidates are few and their handling is heavy).
+template <int D, class F>
+__device__ __forceinline__ void screen_scan_below(const float* tree32, size_t cap, uint32_t n, int dim, const float qf[D],
+                                                  float thr, uint32_t tid, uint32_t nthreads, F&& visit) {
+    for (uint32_t i0 = 4u * tid; i0 < n; i0 += 4u * nthreads) {
+        oxhip_f32x4 e = *reinterpret_cast<const oxhip_f32x4*>(tree32 + i0) - qf[0];
+        oxhip_f32x4 s = e * e;
+#pragma unroll
+        for (int k = 1; k < D; ++k) {
+            if (k < dim) {
+                e = *reinterpret_cast<const oxhip_f32x4*>(tree32 + (size_t)k * cap + i0) - qf[k];
+                s = __builtin_elementwise_fma(e, e, s);
+            }
+        }
+        uint32_t hits = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) hits |= (i0 + (uint32_t)t < n && s[t] <= thr) ? (1u << t) : 0u;
+        for (; hits != 0; hits &= hits - 1) visit(i0 + (uint32_t)(__ffs((int)hits) - 1));
+    }
+}
+
 // Brings the fl32 shadow of one problem's tree up to date (nodes [valid, n)) and returns the magnitude bound M for this
 // launch: the shadowed nodes, the bounds and the goal centre.  Whole workgroup; contains barriers.
 template <int D>

@@ -26,12 +26,13 @@ struct StarShared {
     Best wave_best[kStarWaves];
     Exact wave_exact[kStarWaves];
     uint32_t nb_count;
+    uint32_t shadow_word;
     uint32_t rew_cnt;
     unsigned long long rew_sum;
 };
 
 template <int DIM>
-__global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p_in) {
+__global__ __launch_bounds__(kStarThreads, DIM ? 4 : 1) void rrt_star_kernel(DevParams p_in) {
     constexpr int D = DIM ? DIM : kMaxDim;
     const int dim = DIM ? DIM : (int)p_in.dim;
     const uint32_t prob = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -57,6 +58,12 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p_in) 
     rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
 
     uint32_t n = st.n_nodes;
+    // binary32 shadow of the tree: both scans of an iteration screen over it (rrt_device.hpp) and decide in binary64
+    float* tree32 = p.tree32 + (size_t)prob * p.dim * cap;
+    const ScreenMargins mg = screen_margins(shadow_sync<D>(p, dim, prob, tree, tree32, cap, n, goal_c, &sh.shadow_word, tid, kStarThreads), dim);
+    // find_neighbours' radius test d2 <= thr_search, screened: a node whose binary32 d2 exceeds this cannot pass it
+    const float nb_screen = screen_threshold(mg, sqrt(p.thr_search));
+
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
     for (uint64_t it = 0; it < p.budget; ++it) {
         if (n >= p.max_nodes) { stop = 2; break; }
@@ -65,24 +72,57 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p_in) 
         double q[D];
         sample_state<D>(rng, p, dim, goal_c, q);
 
-        // 3. nearest (rrt_star.rs:189-199): d2 compare, exact post-sqrt fallback on near-ties
+        // 3. nearest (rrt_star.rs:189-199): binary32 screen first (see rrt_stream.hip), else d2 compare with the
+        //    exact post-sqrt fallback on near-ties
         Best best = best_init();
-        for (uint32_t i = tid; i < n; i += kStarThreads) {
-            double c[D];
+        bool screened = false;
+        if (mg.usable) {
+            float qf[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree[(size_t)k * cap + i];
-            best_push(best, dist2<D>(c, q, dim), i);
+            for (int k = 0; k < D; ++k) if (k < dim) qf[k] = (float)q[k];
+            float s1 = __builtin_inff(), s2 = __builtin_inff();
+            uint32_t si = 0xFFFFFFFFu;
+            screen_scan<D>(tree32, cap, n, dim, qf, tid, kStarThreads, [&](uint32_t i, float s) {
+                s2 = __builtin_amdgcn_fmed3f(s, s1, s2);
+                const bool lt = s < s1;
+                s1 = lt ? s : s1;
+                si = lt ? i : si;
+            });
+            best = best_wave_reduce(Best{(double)s1, (double)s2, si});
+            if (lane == 0) sh.wave_best[wave] = best;
+            if (tid == 0) { sh.nb_count = 0; sh.rew_cnt = 0; sh.rew_sum = 0; }
+            __syncthreads();
+            best = sh.wave_best[0];
+#pragma unroll
+            for (int w = 1; w < kStarWaves; ++w) best = best_combine(best, sh.wave_best[w]);
+            screened = screen_clear(mg, best.b1, best.b2);
+            if (!screened) __syncthreads();   // everyone has read wave_best before the binary64 scan rewrites it
         }
-        best = best_wave_reduce(best);
-        if (lane == 0) sh.wave_best[wave] = best;
-        if (tid == 0) { sh.nb_count = 0; sh.rew_cnt = 0; sh.rew_sum = 0; }
-        __syncthreads();
-        best = sh.wave_best[0];
+        if (!screened) {
+            best = best_init();
+            for (uint32_t i = tid; i < n; i += kStarThreads) {
+                double c[D];
 #pragma unroll
-        for (int w = 1; w < kStarWaves; ++w) best = best_combine(best, sh.wave_best[w]);
+                for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree[(size_t)k * cap + i];
+                best_push(best, dist2<D>(c, q, dim), i);
+            }
+            best = best_wave_reduce(best);
+            if (lane == 0) sh.wave_best[wave] = best;
+            if (tid == 0) { sh.nb_count = 0; sh.rew_cnt = 0; sh.rew_sum = 0; }
+            __syncthreads();
+            best = sh.wave_best[0];
+#pragma unroll
+            for (int w = 1; w < kStarWaves; ++w) best = best_combine(best, sh.wave_best[w]);
+        }
         uint32_t nearest;
         double min_dist;
-        if (best_ambiguous(best)) {
+        if (screened) {
+            nearest = best.i1;
+            double c[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree[(size_t)k * cap + nearest];
+            min_dist = sqrt(dist2<D>(c, q, dim));
+        } else if (best_ambiguous(best)) {
             Exact e{__builtin_inf(), 0xFFFFFFFFu};
             for (uint32_t i = tid; i < n; i += kStarThreads) {
                 double c[D];
@@ -139,7 +179,7 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p_in) 
         // The same pass already finds the first choose-parent candidate: the lexicographic minimum of
         // (cost via neighbour, index) among the neighbours cheaper than the nearest node.
         Exact m{__builtin_inf(), 0xFFFFFFFFu};
-        for (uint32_t i = tid; i < n; i += kStarThreads) {
+        auto neighbour = [&](uint32_t i) {   // the reference's test and bookkeeping for node i, in binary64
             double c[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree[(size_t)k * cap + i];
@@ -152,6 +192,14 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p_in) 
                 const double cv = cost[i] + d;
                 if (cv < init_cost && (cv < m.dist || (cv == m.dist && i < m.idx))) { m.dist = cv; m.idx = i; }
             }
+        };
+        if (mg.usable && nb_screen < __builtin_inff()) {
+            float qf[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k < dim) qf[k] = (float)q_new[k];
+            screen_scan_below<D>(tree32, cap, n, dim, qf, nb_screen, tid, kStarThreads, neighbour);
+        } else {
+            for (uint32_t i = tid; i < n; i += kStarThreads) neighbour(i);
         }
         m = exact_wave_reduce(m);
         if (lane == 0) sh.wave_exact[wave] = m;
@@ -194,7 +242,12 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p_in) 
         const uint32_t new_idx = n;
         if (tid == 0) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) if (k < dim) tree[(size_t)k * cap + n] = q_new[k];
+            for (int k = 0; k < D; ++k) {
+                if (k < dim) {
+                    tree[(size_t)k * cap + n] = q_new[k];
+                    tree32[(size_t)k * cap + n] = (float)q_new[k];
+                }
+            }
             parent[n] = (int32_t)best_parent;
             cost[n] = min_cost;
         }
@@ -243,6 +296,8 @@ __global__ __launch_bounds__(kStarThreads) void rrt_star_kernel(DevParams p_in) 
         st.draws = rng.pos;
         st.stop_reason = stop;
         p.state[prob] = st;
+        p.shadow_state[2 * (size_t)prob] = n;
+        p.shadow_state[2 * (size_t)prob + 1] = sh.shadow_word;
     }
 }
 

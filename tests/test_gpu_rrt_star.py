@@ -125,6 +125,38 @@ def test_rrt_star_search_radius_extremes(star_golden, radius):
         assert np.array_equal(bits(gs), bits(rs)) and np.array_equal(gp, rp)
 
 
+@pytest.mark.parametrize("scale,offset", [(1.0, 1.0e3), (1.0, 1.0e6), (1.0e-12, 0.0), (1.0e18, 0.0), (1.0e40, 0.0)])
+def test_rrt_star_translated_and_scaled_spaces(star_golden, scale, offset):
+    """The sphere-field scene moved or scaled into the regimes of the binary32 screens' error model (nearest scan and
+    radius search both screen over an fl32 shadow of the tree and decide in binary64): far from the origin binary32
+    separates nothing and every scan takes the binary64 path; beyond 1e15 the screen is switched off; 1e-12 sits at
+    the subnormal end.  Trees, parents after rewiring and costs must not move by a bit."""
+    B = star_golden["config2"]["params"]
+    t = lambda v: [float(x) * scale + offset for x in v]
+    P = dict(B)
+    P["bounds"] = [t(b) for b in B["bounds"]]
+    P["start"], P["goal_c"] = t(B["start"]), t(B["goal_c"])
+    P["max_distance"], P["goal_r"], P["search_radius"] = B["max_distance"] * scale, B["goal_r"] * scale, B["search_radius"] * scale
+    c, r = params_spheres(B)
+    c, r = np.asarray(c) * scale + offset, np.asarray(r) * scale
+    n_prob = 4
+    g = capi.RRTBatch(P["dim"], P["bounds"], P["max_distance"], P["goal_bias"], n_prob, 2000, P["fraction"], False, 9, 300, 0,
+                      capi.KERNEL_AUTO, capi.PLANNER_RRT_STAR, P["search_radius"])
+    g.set_spheres(c, r)
+    g.setup(P["start"], P["goal_c"], P["goal_r"])
+    g.solve(600)
+    cts = g.counts()
+    for p in range(n_prob):
+        o = orc.OracleRRTStar(P["dim"], P["bounds"], P["max_distance"], P["goal_bias"], P["search_radius"], P["fraction"],
+                              2000, False, 9, 300 + p)
+        o.set_spheres(c, r)
+        o.setup(P["start"], P["goal_c"], P["goal_r"])
+        o.solve(600)
+        assert o.num_nodes > 100
+        assert_same(g, p, o, cts)
+    g.close()
+
+
 def test_rrt_star_rewiring_shortens_costs(star_golden):
     """a property of the algorithm, checked on the device result: with a useful search radius the goal node's
     cost-to-come is not worse than without rewiring / parent choice (radius 0) on the same sample stream"""
