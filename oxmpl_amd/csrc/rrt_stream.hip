@@ -196,6 +196,10 @@ void launch_rrt_stream(const DevParams& p, hipStream_t stream) {
     switch (p.dim) {
         case 2: hipLaunchKernelGGL(rrt_stream_kernel<2>, grid, block, 0, stream, p); break;
         case 3: hipLaunchKernelGGL(rrt_stream_kernel<3>, grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL(rrt_stream_kernel<4>, grid, block, 0, stream, p); break;
+        case 5: hipLaunchKernelGGL(rrt_stream_kernel<5>, grid, block, 0, stream, p); break;
+        case 6: hipLaunchKernelGGL(rrt_stream_kernel<6>, grid, block, 0, stream, p); break;
+        case 7: hipLaunchKernelGGL(rrt_stream_kernel<7>, grid, block, 0, stream, p); break;
         default: hipLaunchKernelGGL(rrt_stream_kernel<0>, grid, block, 0, stream, p); break;
     }
 }
