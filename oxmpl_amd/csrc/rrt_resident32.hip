@@ -46,6 +46,14 @@ constexpr int kRing32 = OXHIP_RING32;        // queries in flight (power of two)
 #define OXHIP_C32 14
 #endif
 constexpr int kPipeThreads32 = kScanThreads + 128;   // + the resolver wave + the sampler wave
+#ifndef OXHIP_BATCH32
+#define OXHIP_BATCH32 4
+#endif
+constexpr int kBatch32 = OXHIP_BATCH32;             // queries one scanner pass covers = queries the resolver handles side by side
+constexpr int kRowLanes = 64 / kBatch32;            // resolver lanes per query: a DPP row (16) or half-row (8)
+constexpr uint32_t kRowMask = (1u << kRowLanes) - 1u;
+static_assert(kBatch32 == 4 || kBatch32 == 8, "a query's lane group is a DPP row or half-row");
+static_assert(kRowLanes >= kScanWaves, "one lane per scanner wave's result");
 constexpr int kS32 = OXHIP_S32, kC32 = OXHIP_C32;   // register rows of the heavy / of every scanner wave
 
 struct alignas(16) WavePub32 {   // one wave's screen result for one query (one 16-byte LDS store)
@@ -121,6 +129,25 @@ __device__ __forceinline__ void screen_push(Screen& v, float s, uint32_t slot) {
     v.b1 = key < v.b1 ? key : v.b1;
 }
 
+// minima over a query's lane group (every lane of the group ends up with it): 16 lanes = a DPP row, 8 = a half-row
+__device__ __forceinline__ uint32_t grp_min_u32(uint32_t v) {
+    v = dpp_umin_step<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_umin_step<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_umin_step<0x141, 0xf>(v);   // row_half_mirror
+    if (kRowLanes == 16) v = dpp_umin_step<0x140, 0xf>(v);   // row_mirror
+    return v;
+}
+__device__ __forceinline__ double grp_min_f64(double v) {
+    v = dpp_min_step<0xB1, 0xf>(v);
+    v = dpp_min_step<0x4E, 0xf>(v);
+    v = dpp_min_step<0x141, 0xf>(v);
+    if (kRowLanes == 16) v = dpp_min_step<0x140, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t grp_ballot(bool pred, uint32_t row) {
+    return (uint32_t)(__ballot(pred) >> (kRowLanes * row)) & kRowMask;
+}
+
 // The resolver's view of one query's screen, for the 16-lane DPP row the caller sits in (lanes sub < 8 read the
 // eight waves' results).  Row-uniform outputs.
 struct RowScreen {
@@ -140,13 +167,13 @@ __device__ __forceinline__ RowScreen row_screen(const WavePub32* pubs, uint32_t 
     const uint32_t k1 = inS ? mine.k1 : kKeyInf;
     const uint32_t k2 = inS ? mine.k2 : kKeyInf;
     const uint32_t nc = inS ? mine.nc : 0xFFFFFFFFu;
-    const uint32_t K1 = row_min_u32(k1);
-    const uint32_t eq = (uint32_t)(__ballot(inS && k1 == K1) >> (16 * row)) & 0xFFFFu;
+    const uint32_t K1 = grp_min_u32(k1);
+    const uint32_t eq = grp_ballot(inS && k1 == K1, row);
     const uint32_t wsub = eq ? (uint32_t)(__ffs((int)eq) - 1) : 0u;
-    const uint32_t K2 = row_min_u32((inS && sub == wsub) ? k2 : k1);
+    const uint32_t K2 = grp_min_u32((inS && sub == wsub) ? k2 : k1);
     RowScreen r;
-    r.cand = (uint32_t)__shfl((int)mine.i1, (int)(16 * row + wsub), 64);
-    r.bmin = row_min_u32(nc);
+    r.cand = (uint32_t)__shfl((int)mine.i1, (int)(kRowLanes * row + wsub), 64);
+    r.bmin = grp_min_u32(nc);
     const float v1 = bits_f32(K1 & ~kSlotMask), v2 = bits_f32(K2 & ~kSlotMask);
     // v_sqrt_f32 (1 ulp; a subnormal argument may come back as 0, which the 1e-18 inside A covers): its 2^-22 is in r_lo / r_hi
     const double d1 = (double)__builtin_amdgcn_sqrtf(v1), d2 = (double)__builtin_amdgcn_sqrtf(v2);
@@ -159,7 +186,7 @@ template <int DIM, int S, int C, bool STAMP>
 __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParams p) {
     constexpr int D = DIM;
     static_assert(S <= 32, "the slot number lives in 5 key bits");
-    static_assert(kBatch == 4, "queries are screened in pairs and reduced four at a time");
+
     const uint32_t prob = blockIdx.x;
     const uint32_t tid = threadIdx.x;
     const uint32_t wave = uni(tid >> 6), lane = tid & 63;
@@ -209,8 +236,8 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
 
         uint64_t t_wait = 0, t_work = 0, t_pre = 0, t_scan = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
         uint32_t seen_sampled = 0;
-        for (uint32_t j = 0; j < budget; j += kBatch) {
-            const uint32_t nb = (budget - j < (uint32_t)kBatch) ? (budget - j) : (uint32_t)kBatch;
+        for (uint32_t j = 0; j < budget; j += kBatch32) {
+            const uint32_t nb = (budget - j < (uint32_t)kBatch32) ? (budget - j) : (uint32_t)kBatch32;
             const uint32_t need = j + nb;
             // wait until the pass's queries are sampled (implies their ring slots were consumed kRing32 queries ago)
             for (uint32_t spins = 0; seen_sampled < need; ++spins) {
@@ -239,17 +266,17 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
             }
             n_local = nc;
             // the pass's queries, two per packed register
-            f32x2 q[kBatch / 2][D];
+            f32x2 q[kBatch32 / 2][D];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
+            for (int b = 0; b < kBatch32; ++b) {
                 const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kRing32 - 1);
 #pragma unroll
                 for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = sh.qring[slot].qf[k];   // same value in every lane
             }
             const uint32_t nslots = Lay::slots_in_use(wave, nc);
-            Screen sc[kBatch];
+            Screen sc[kBatch32];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) sc[b] = Screen{kKeyInf, kKeyInf};
+            for (int b = 0; b < kBatch32; ++b) sc[b] = Screen{kKeyInf, kKeyInf};
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_pre += now - t_mark; t_mark = now; }
             // screen (rrt.rs:187-196 in binary32): groups of kGroup slots under one uniform branch
 #pragma unroll
@@ -258,7 +285,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
 #pragma unroll
                     for (int s = g0; s < g0 + group_len<S, C>(g0); ++s) {
 #pragma unroll
-                        for (int bp = 0; bp < kBatch / 2; ++bp) {
+                        for (int bp = 0; bp < kBatch32 / 2; ++bp) {
                             f32x2 e = (f32x2){tr[0][s], tr[0][s]} - q[bp][0];
                             f32x2 acc = e * e;
 #pragma unroll
@@ -274,20 +301,33 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
             }
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_scan += now - t_mark; t_mark = now; }
             // reduce: the wave's smallest key, its lane, and the smallest of everything else
-            uint32_t k1w[kBatch], k2w[kBatch];
-            int wl[kBatch];
+            uint32_t k1w[kBatch32], k2w[kBatch32];
+            int wl[kBatch32];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) k1w[b] = sc[b].b1;
-            wave_min4_u32(k1w);
+            for (int b0 = 0; b0 < kBatch32; b0 += 4) {
+                uint32_t t4[4];
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
+                for (int t = 0; t < 4; ++t) t4[t] = sc[b0 + t].b1;
+                wave_min4_u32(t4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) k1w[b0 + t] = t4[t];
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch32; ++b) {
                 const uint64_t eqm = __ballot(sc[b].b1 == k1w[b]);
                 wl[b] = __ffsll((unsigned long long)eqm) - 1;   // eqm != 0: the minimum is attained
-                k2w[b] = (int)lane == wl[b] ? sc[b].h2 : sc[b].b1;
             }
-            wave_min4_u32(k2w);
 #pragma unroll
-            for (int b = 0; b < kBatch; ++b) {
+            for (int b0 = 0; b0 < kBatch32; b0 += 4) {
+                uint32_t t4[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) t4[t] = (int)lane == wl[b0 + t] ? sc[b0 + t].h2 : sc[b0 + t].b1;
+                wave_min4_u32(t4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) k2w[b0 + t] = t4[t];
+            }
+#pragma unroll
+            for (int b = 0; b < kBatch32; ++b) {
                 if ((uint32_t)b < nb) {
                     const uint32_t slot = (j + (uint32_t)b) & (kRing32 - 1);
                     if (lane == 0) {
@@ -394,7 +434,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
     uint32_t n = st.n_nodes;
     uint32_t jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
-    const uint32_t row = lane >> 4, sub = lane & 15;
+    const uint32_t row = lane / (uint32_t)kRowLanes, sub = lane % (uint32_t)kRowLanes;
     uint64_t t_wait = 0, t_work = 0, t_comb = 0, n_amb = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
@@ -496,8 +536,8 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
     while (jr < budget) {
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
 
-        // the scanners publish kBatch queries per pass: resolve them as one batch
-        const uint32_t nbq = (budget - jr < (uint32_t)kBatch) ? (budget - jr) : (uint32_t)kBatch;
+        // the scanners publish kBatch32 queries per pass: resolve them as one batch
+        const uint32_t nbq = (budget - jr < (uint32_t)kBatch32) ? (budget - jr) : (uint32_t)kBatch32;
         uint32_t spins = 0;
         for (uint32_t b = 0; b < nbq; ++b) {
             while (uni(lds_peek(&sh.done[(jr + b) & (kRing32 - 1)])) < (uint32_t)kScanWaves && spins <= kMaxSpins) {
@@ -508,7 +548,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
         if (spins > kMaxSpins) { stop = 4; break; }  // OXHIP_STOP_INTERNAL: a scanner never published (bug guard)
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_wait += now - t_mark; t_mark = now; }
 
-        // ---- row-parallel phase: DPP row r (16 lanes) works on query jr + r against the tree of n0 nodes
+        // ---- row-parallel phase: lane group r (a DPP row or half-row) works on query jr + r against the tree of n0 nodes
         const uint32_t n0 = n;
         const bool active = row < nbq;
         const uint32_t slot_r = (jr + (active ? row : 0u)) & (kRing32 - 1);
@@ -530,27 +570,27 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
         // nodes committed after the oldest snapshot (at most a few): lanes of the row stride over them
         Scan pd{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
         if (active) {
-            for (uint32_t i = bmin_r + sub; i < n0; i += 16) {
+            for (uint32_t i = bmin_r + sub; i < n0; i += (uint32_t)kRowLanes) {
                 double c[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) c[k] = sh.newn[i & 63][k];
                 scan_push(pd, dist2<D>(c, q, DIM), i);  // ascending i: ties keep the lower index
             }
         }
-        const double g_r = row_min_f64(pd.b1 < pb ? pd.b1 : pb);
+        const double g_r = grp_min_f64(pd.b1 < pb ? pd.b1 : pb);
         const uint32_t hb = hi32(g_r) + 1;
         const bool nearS = inS && hi32(pb) <= hb;
         const bool nearP = active && pd.slot != kNoNode && hi32(pd.b1) <= hb;
-        const uint32_t rowS = (uint32_t)(__ballot(nearS) >> (16 * row)) & 0xFFFFu;
-        const uint32_t rowP = (uint32_t)(__ballot(nearP) >> (16 * row)) & 0xFFFFu;
+        const uint32_t rowS = grp_ballot(nearS, row);
+        const uint32_t rowP = grp_ballot(nearP, row);
         const bool from_scan = rowS != 0;
         const uint32_t wsub = from_scan ? 0u : (rowP ? (uint32_t)(__ffs((int)rowP) - 1) : 0u);
-        const int src_lane = (int)(16 * row + wsub);
+        const int src_lane = (int)(kRowLanes * row + wsub);
         const uint32_t wP = (uint32_t)__shfl((int)pd.slot, src_lane, 64);
         const uint32_t nearest_r = from_scan ? pidxS : wP;
         // ambiguous iff the screen could not name a winner, or a second node is near the binary64 minimum
         const bool amb_l = (nearP && pd.slot != nearest_r) || (active && pd.h2 <= hb);
-        const bool amb_r = !clear_r || ((uint32_t)(__ballot(amb_l) >> (16 * row)) & 0xFFFFu) != 0 || (rowS == 0 && rowP == 0);
+        const bool amb_r = !clear_r || grp_ballot(amb_l, row) != 0 || (rowS == 0 && rowP == 0);
         double q_near[D], qn[D], mid[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) q_near[k] = from_scan ? cc[k] : sh.newn[nearest_r & 63][k];
@@ -558,14 +598,14 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
         lerp<DIM>(q_near, qn, 0.5, mid, DIM);
         bool maybe_l = false;
         if (nobs > 0) {
-            for (uint32_t o = sub; o < 64; o += 16) {
+            for (uint32_t o = sub; o < 64; o += (uint32_t)kRowLanes) {
                 double c[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k) c[k] = sh.obs[k][o];
                 maybe_l = maybe_l || sphere_maybe_hit<DIM>(c, sh.obs[D][o], mid);
             }
         }
-        const bool maybe_r = extras || (((uint32_t)(__ballot(maybe_l) >> (16 * row)) & 0xFFFFu) != 0);
+        const bool maybe_r = extras || grp_ballot(maybe_l, row) != 0;
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_comb += now - t_mark; t_mark = now; }
 
         // ---- batch commit: when no query of a full batch is ambiguous, no node accepted earlier in the batch comes
@@ -573,16 +613,16 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
         //      the four iterations are independent given the row results, and the per-query bookkeeping below (the
         //      "sequential phase", ~900 cycles per query of scalar code) collapses into one pass.  Anything else falls
         //      through to the sequential phase, which is the reference's order literally.
-        if (nbq == (uint32_t)kBatch && __ballot(amb_r) == 0) {
+        if (nbq == (uint32_t)kBatch32 && __ballot(amb_r) == 0) {
             // motion checks of the rows the midpoint filter could not clear (is_valid is pure: the order is free)
-            uint32_t okmask = (1u << kBatch) - 1u;
+            uint32_t okmask = (1u << kBatch32) - 1u;
             if (nobs > 0) {
 #pragma unroll
-                for (int r = 0; r < kBatch; ++r) {
-                    if (__builtin_amdgcn_readlane(maybe_r ? 1 : 0, 16 * r) != 0) {
+                for (int r = 0; r < kBatch32; ++r) {
+                    if (__builtin_amdgcn_readlane(maybe_r ? 1 : 0, kRowLanes * r) != 0) {
                         double a[D], bq[D];
 #pragma unroll
-                        for (int k = 0; k < D; ++k) { a[k] = readlane_f64(q_near[k], 16 * r); bq[k] = readlane_f64(qn[k], 16 * r); }
+                        for (int k = 0; k < D; ++k) { a[k] = readlane_f64(q_near[k], kRowLanes * r); bq[k] = readlane_f64(qn[k], kRowLanes * r); }
                         if (!motion_lanes<DIM>(p, lane, a, bq, oc, othr, ofilt, ns64)) okmask &= ~(1u << r);
                     }
                 }
@@ -596,11 +636,11 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
                 // would a node accepted earlier in the batch be (nearly) as close to this row's query as its nearest?
                 bool conflict_l = false;
 #pragma unroll
-                for (int a = 0; a < kBatch - 1; ++a) {
+                for (int a = 0; a < kBatch32 - 1; ++a) {
                     double ca[D];
 #pragma unroll
-                    for (int k = 0; k < D; ++k) ca[k] = readlane_f64(qn[k], 16 * a);
-                    const bool a_new = ((okmask >> a) & 1u) != 0 && readlane_f64(g_r, 16 * a) != 0.0;   // accepted and not a duplicate
+                    for (int k = 0; k < D; ++k) ca[k] = readlane_f64(qn[k], kRowLanes * a);
+                    const bool a_new = ((okmask >> a) & 1u) != 0 && readlane_f64(g_r, kRowLanes * a) != 0.0;   // accepted and not a duplicate
                     conflict_l = conflict_l || (a_new && row > (uint32_t)a && hi32(dist2<D>(ca, q, DIM)) <= hb);
                 }
                 const bool hit_l = ok_l && dist2<D>(qn, goal_c, DIM) <= goal_thr;
@@ -627,20 +667,20 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
             if (!special) {
                 uint64_t h = st.checksum;
 #pragma unroll
-                for (int r = 0; r < kBatch; ++r) {
-                    h = fnv_mix(h, (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)nearest_r, 16 * r));
+                for (int r = 0; r < kBatch32; ++r) {
+                    h = fnv_mix(h, (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)nearest_r, kRowLanes * r));
 #pragma unroll
-                    for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(readlane_f64(qn[k], 16 * r))));
+                    for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(readlane_f64(qn[k], kRowLanes * r))));
                     h = fnv_mix(h, (uint64_t)((okmask >> r) & 1u));
                 }
                 st.checksum = h;
-                st.iterations += kBatch;
+                st.iterations += kBatch32;
                 st.accepted += (uint64_t)__popc(okmask);
-                draws_done = uni64((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_r, 16 * (kBatch - 1)) |
-                                   ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_r >> 32), 16 * (kBatch - 1)) << 32));
-                if (lane < (uint32_t)kBatch) lds_post(&sh.done[(jr + lane) & (kRing32 - 1)], 0);   // free the slots ...
-                if (lane == 0) lds_post(&sh.resolved, jr + (uint32_t)kBatch);                     // ... before they are handed out again
-                jr += (uint32_t)kBatch;
+                draws_done = uni64((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_r, kRowLanes * (kBatch32 - 1)) |
+                                   ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_r >> 32), kRowLanes * (kBatch32 - 1)) << 32));
+                if (lane < (uint32_t)kBatch32) lds_post(&sh.done[(jr + lane) & (kRing32 - 1)], 0);   // free the slots ...
+                if (lane == 0) lds_post(&sh.resolved, jr + (uint32_t)kBatch32);                     // ... before they are handed out again
+                jr += (uint32_t)kBatch32;
                 if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
                 continue;
             }
@@ -648,19 +688,19 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
 
         // ---- sequential phase: commit in query order; a node committed earlier in this batch that is
         //      closer (or near-tied) to a later query forces that query through resolve_one
-        double cn[kBatch][D];   // coordinates the scanners will hold for the nodes committed in this batch
-        bool cn_valid[kBatch];
+        double cn[kBatch32][D];   // coordinates the scanners will hold for the nodes committed in this batch
+        bool cn_valid[kBatch32];
 #pragma unroll
-        for (int b = 0; b < kBatch; ++b) cn_valid[b] = false;
+        for (int b = 0; b < kBatch32; ++b) cn_valid[b] = false;
         bool leave = false;
         uint32_t processed = 0;
 #pragma unroll
-        for (int b = 0; b < kBatch; ++b) {
+        for (int b = 0; b < kBatch32; ++b) {
             if (!leave && (uint32_t)b < nbq) {
                 if (!p.freeze && n >= p.max_nodes) { stop = 2; leave = true; }
             }
             if (!leave && (uint32_t)b < nbq) {
-                const int l0 = 16 * b;
+                const int l0 = kRowLanes * b;
                 const uint32_t slot = (jr + (uint32_t)b) & (kRing32 - 1);
                 const double g_b = readlane_f64(g_r, l0);
                 double q_b[D];
