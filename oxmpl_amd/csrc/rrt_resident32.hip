@@ -47,13 +47,20 @@ constexpr int kRing32 = OXHIP_RING32;        // queries in flight (power of two)
 #endif
 constexpr int kPipeThreads32 = kScanThreads + 128;   // + the resolver wave + the sampler wave
 #ifndef OXHIP_BATCH32
-#define OXHIP_BATCH32 4
+#define OXHIP_BATCH32 8
 #endif
 constexpr int kBatch32 = OXHIP_BATCH32;             // queries one scanner pass covers = queries the resolver handles side by side
 constexpr int kRowLanes = 64 / kBatch32;            // resolver lanes per query: a DPP row (16) or half-row (8)
 constexpr uint32_t kRowMask = (1u << kRowLanes) - 1u;
 static_assert(kBatch32 == 4 || kBatch32 == 8, "a query's lane group is a DPP row or half-row");
 static_assert(kRowLanes >= kScanWaves, "one lane per scanner wave's result");
+#ifndef OXHIP_SCAN_PRIO
+#define OXHIP_SCAN_PRIO 16   // a scanner wave whose lead over the resolver is below this many queries runs at raised priority (0: off)
+#endif
+#ifndef OXHIP_OLDER32
+#define OXHIP_OLDER32 0
+#endif
+constexpr bool kOlder32 = OXHIP_OLDER32 != 0;        // which waves hold the extra rows (Layout)
 constexpr int kS32 = OXHIP_S32, kC32 = OXHIP_C32;   // register rows of the heavy / of every scanner wave
 
 struct alignas(16) WavePub32 {   // one wave's screen result for one query (one 16-byte LDS store)
@@ -75,7 +82,7 @@ struct PipeShared32 {
     uint32_t rng_buf[16][64];
     QSlot32<DIM> qring[kRing32];
     WavePub32 pub[kRing32][kScanWaves];
-    uint32_t done[kRing32];
+    uint32_t wave_done[kScanWaves];      // queries each scanner wave has published so far (monotonic, one plain store per pass)
     double newn[64][DIM];
     double obs[DIM + 1][64];
     uint32_t sampled, resolved, committed, stop_flag;
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
     uint8_t* skip = p.skip + (size_t)prob * cap;
     const uint32_t budget = (uint32_t)p.budget;  // the host keeps a launch's budget below 2^31
 
-    if (tid < kRing32) sh.done[tid] = 0;
+    if (tid < (uint32_t)kScanWaves) sh.wave_done[tid] = 0;
     if (tid == 0) {
         sh.sampled = 0;
         sh.resolved = 0;
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
 
     if (wave < kScanWaves) {
         // ================================================================= scanner waves
-        using Lay = Layout<S, C>;
+        using Lay = Layout<S, C, kOlder32>;
         uint32_t n_local = st0.n_nodes;
         float tr[DIM][S];
         uint32_t mab = 0;
@@ -246,6 +253,12 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
                 if (seen_sampled < need) __builtin_amdgcn_s_sleep(2);
             }
             if (seen_sampled < need) break;  // stop requested
+#if OXHIP_SCAN_PRIO
+            // two scanner waves share a SIMD and the older one wins every issue conflict: it races ahead, then idles at the
+            // ring, while the younger one -- the wave the resolver ends up waiting for -- crawls.  The wave with the
+            // smaller lead over the resolver takes the higher priority for this pass.
+            if (j - uni(lds_peek(&sh.resolved)) < (uint32_t)OXHIP_SCAN_PRIO) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_wait += now - t_mark; t_mark = now; }
             // absorb the nodes committed since this wave's last snapshot (the owner lane takes each)
             const uint32_t nc = uni(lds_peek(&sh.committed));
@@ -271,7 +284,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
             for (int b = 0; b < kBatch32; ++b) {
                 const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kRing32 - 1);
 #pragma unroll
-                for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = sh.qring[slot].qf[k];   // same value in every lane
+                for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = bits_f32(uni(f32_bits(sh.qring[slot].qf[k])));   // wave-uniform: scalar registers
             }
             const uint32_t nslots = Lay::slots_in_use(wave, nc);
             Screen sc[kBatch32];
@@ -337,10 +350,10 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
                         out.i1 = Lay::node_index(wave, (uint32_t)wl[b], k1w[b] & kSlotMask);
                         out.nc = nc;
                         sh.pub[slot][wave] = out;
-                        lds_bump(&sh.done[slot]);
                     }
                 }
             }
+            if (lane == 0) lds_post(&sh.wave_done[wave], need);   // after the records (LDS is in order within a wave)
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
         }
         if (STAMP && p.dbg && prob == 0 && lane == 0) {
@@ -539,11 +552,10 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
         // the scanners publish kBatch32 queries per pass: resolve them as one batch
         const uint32_t nbq = (budget - jr < (uint32_t)kBatch32) ? (budget - jr) : (uint32_t)kBatch32;
         uint32_t spins = 0;
-        for (uint32_t b = 0; b < nbq; ++b) {
-            while (uni(lds_peek(&sh.done[(jr + b) & (kRing32 - 1)])) < (uint32_t)kScanWaves && spins <= kMaxSpins) {
-                __builtin_amdgcn_s_sleep(1);
-                ++spins;
-            }
+        while (__ballot(lane < (uint32_t)kScanWaves && lds_peek(&sh.wave_done[lane & (kScanWaves - 1)]) < jr + nbq) != 0 &&
+               spins <= kMaxSpins) {   // some scanner wave has not published this batch yet
+            __builtin_amdgcn_s_sleep(1);
+            ++spins;
         }
         if (spins > kMaxSpins) { stop = 4; break; }  // OXHIP_STOP_INTERNAL: a scanner never published (bug guard)
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_wait += now - t_mark; t_mark = now; }
@@ -678,8 +690,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
                 st.accepted += (uint64_t)__popc(okmask);
                 draws_done = uni64((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_r, kRowLanes * (kBatch32 - 1)) |
                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_r >> 32), kRowLanes * (kBatch32 - 1)) << 32));
-                if (lane < (uint32_t)kBatch32) lds_post(&sh.done[(jr + lane) & (kRing32 - 1)], 0);   // free the slots ...
-                if (lane == 0) lds_post(&sh.resolved, jr + (uint32_t)kBatch32);                     // ... before they are handed out again
+                if (lane == 0) lds_post(&sh.resolved, jr + (uint32_t)kBatch32);   // the sampler may hand the slots out again
                 jr += (uint32_t)kBatch32;
                 if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
                 continue;
@@ -701,7 +712,6 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
             }
             if (!leave && (uint32_t)b < nbq) {
                 const int l0 = kRowLanes * b;
-                const uint32_t slot = (jr + (uint32_t)b) & (kRing32 - 1);
                 const double g_b = readlane_f64(g_r, l0);
                 double q_b[D];
 #pragma unroll
@@ -764,10 +774,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
                         }
                     }
                 }
-                if (lane == 0) {
-                    lds_post(&sh.done[slot], 0);                 // free the slot ...
-                    lds_post(&sh.resolved, jr + (uint32_t)b + 1); // ... before the sampler may hand it out again
-                }
+                if (lane == 0) lds_post(&sh.resolved, jr + (uint32_t)b + 1);   // the sampler may hand the slot out again
                 ++processed;
                 if (hit && p.stop_at_goal) { stop = 0; leave = true; }
             }
@@ -792,7 +799,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
 static int pick_slots32(uint32_t cap) {
     const uint32_t need = (cap + kScanThreads - 1) / kScanThreads;
     if (need <= 4) return 4;
-    if (cap <= Layout<kS32, kC32>::kCapacity) return kS32;
+    if (cap <= Layout<kS32, kC32, kOlder32>::kCapacity) return kS32;
     return 0;
 }
 

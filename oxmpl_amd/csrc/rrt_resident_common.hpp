@@ -88,23 +88,25 @@ __device__ __forceinline__ void store_slot(const double (&tr)[DIM][S], uint32_t 
 // six waves 21: rows 0..16 span all 512 threads, rows 17..20 only the 384 threads of waves
 // 1,2,3,5,6,7 (17*512 + 4*384 = 10,240 nodes).  Smaller instantiations use the plain even layout.
 // (C = rows every wave holds; the binary32 kernel, whose scans are cheaper relative to the resolver's work, uses 22 / 14.)
-template <int S, int C = (S == 21 ? 17 : S)>
+// OLDER = true: the extra rows go to waves 0..3 instead -- the older wave of each SIMD, which wins every issue conflict
+// with its younger neighbour (w + 4) and would otherwise idle at the ring while that one is still scanning.
+template <int S, int C = (S == 21 ? 17 : S), bool OLDER = false>
 struct Layout {
     static constexpr bool kUneven = (C != S);
     static constexpr uint32_t kCommon = (uint32_t)C;   // rows every wave holds
-    static constexpr uint32_t kHeavyThreads = 384;
+    static constexpr uint32_t kHeavyThreads = OLDER ? 256 : 384;
     static constexpr uint32_t kCapacity = (uint32_t)C * 512u + (uint32_t)(S - C) * kHeavyThreads;
-    __device__ static __forceinline__ bool heavy(uint32_t wave) { return !kUneven || (wave & 3u) != 0; }
+    __device__ static __forceinline__ bool heavy(uint32_t wave) { return !kUneven || (OLDER ? wave < 4u : (wave & 3u) != 0); }
     __device__ static __forceinline__ uint32_t node_index(uint32_t wave, uint32_t lane, uint32_t slot) {
         if (slot < kCommon) return slot * 512u + wave * 64u + lane;
-        const uint32_t hw = wave - 1u - (wave > 4u ? 1u : 0u);  // waves 1,2,3,5,6,7 -> 0..5
+        const uint32_t hw = OLDER ? wave : wave - 1u - (wave > 4u ? 1u : 0u);  // waves 1,2,3,5,6,7 -> 0..5
         return kCommon * 512u + (slot - kCommon) * kHeavyThreads + hw * 64u + lane;
     }
     __device__ static __forceinline__ void locate(uint32_t i, uint32_t& thread, uint32_t& slot) {
         if (i < kCommon * 512u) { thread = i & 511u; slot = i >> 9; return; }
         const uint32_t r = i - kCommon * 512u, c = r % kHeavyThreads, hw = c >> 6;
         slot = kCommon + r / kHeavyThreads;
-        thread = (hw + 1u + (hw >= 3u ? 1u : 0u)) * 64u + (c & 63u);
+        thread = OLDER ? c : (hw + 1u + (hw >= 3u ? 1u : 0u)) * 64u + (c & 63u);
     }
     __device__ static __forceinline__ uint32_t slots_in_use(uint32_t wave, uint32_t n) {
         if (n <= kCommon * 512u) return (n + 511u) >> 9;
