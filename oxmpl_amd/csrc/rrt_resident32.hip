@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
     uint32_t jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
     const uint32_t row = lane / (uint32_t)kRowLanes, sub = lane % (uint32_t)kRowLanes;
-    uint64_t t_wait = 0, t_work = 0, t_comb = 0, n_amb = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
+    uint64_t t_wait = 0, t_work = 0, t_comb = 0, n_amb = 0, n_seq = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
     Margins mg;
@@ -699,6 +699,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
 
         // ---- sequential phase: commit in query order; a node committed earlier in this batch that is
         //      closer (or near-tied) to a later query forces that query through resolve_one
+        if (STAMP) ++n_seq;
         double cn[kBatch32][D];   // coordinates the scanners will hold for the nodes committed in this batch
         bool cn_valid[kBatch32];
 #pragma unroll
@@ -790,7 +791,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
         st.stop_reason = stop;
         p.state[prob] = st;
         if (STAMP && p.dbg && prob == 0) {
-            p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_comb; p.dbg[4] = n_amb; p.dbg[7] = st.iterations;
+            p.dbg[5] = n_seq; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_comb; p.dbg[4] = n_amb; p.dbg[7] = st.iterations;
         }
     }
 }

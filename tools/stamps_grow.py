@@ -16,6 +16,6 @@ for target in (2000, 4000, 6000):
     it = int(s[7])
     n = int(gpu.counts()["nodes"][0])
     print("after %5d iterations (n=%5d): kernel %.3f ms; resolver sample %.0f wait %.0f combine %.0f rest %.0f cyc/iter; "
-          "scanner0 wait %.0f scan %.0f; scanner5 wait %.0f scan %.0f"
+          "scanner0 wait %.0f scan %.0f; scanner5 wait %.0f scan %.0f; batches through the sequential path %d"
           % (it, n, gpu.last_timing()["kernel_ms"], int(s[0]) / target, int(s[1]) / target, int(s[3]) / target,
-             int(s[2]) / target, int(s[16]) / target, int(s[24]) / target, int(s[21]) / target, int(s[29]) / target))
+             int(s[2]) / target, int(s[16]) / target, int(s[24]) / target, int(s[21]) / target, int(s[29]) / target, int(s[5])))
