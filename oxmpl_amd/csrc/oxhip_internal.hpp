@@ -60,7 +60,8 @@ struct PrmState {            // persists in HBM between launches
     uint32_t pad;
 };
 struct PrmArgs {
-    double* ms;              // milestones, AoS [cap][dim] (the i side of the pair search is read by scalar loads)
+    double* ms;              // milestones, AoS [cap][dim]
+    float* ms32;             // fl32(ms), same layout: what the pair search screens with (its i side is read by scalar loads)
     uint32_t cap;
     uint32_t n_target;       // sample until the roadmap holds this many milestones ...
     uint64_t max_samples;    // ... or this many samples were drawn

@@ -24,6 +24,7 @@ struct oxhip_prm {
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
     DevBuf<double> ms, sph_c, sph_thr, sph_r, box_lo, box_hi;
+    DevBuf<float> ms32;   // fl32 shadow of the milestones (pair-search screen)
     double maxabs = 1.0;      // largest |coordinate| of bounds and sphere centres (midpoint filter margin)
     DevBuf<PrmState> state;
     DevBuf<uint2> cand;
@@ -198,6 +199,7 @@ int32_t oxhip_prm_create(const oxhip_prm_config* cfg, oxhip_prm** out) {
     chk(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& ev : h->ev) chk(hipEventCreate(&ev));
     chk(h->ms.alloc((size_t)dim * cap));
+    chk(h->ms32.alloc((size_t)dim * cap));
     chk(h->state.alloc(1));
     chk(h->flags.alloc(cap));
     chk(h->start_valid.alloc(1));
@@ -208,6 +210,7 @@ int32_t oxhip_prm_create(const oxhip_prm_config* cfg, oxhip_prm** out) {
         return fail(OXHIP_ERR_HIP, msg);
     }
     h->args.ms = h->ms.p;
+    h->args.ms32 = h->ms32.p;
     h->args.cap = cap;
     h->args.stream = cfg->stream;
     h->args.state = h->state.p;

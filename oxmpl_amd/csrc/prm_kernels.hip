@@ -20,7 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <type_traits>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(kSpecThreads) void prm_sample_compact_kernel(PrmArg
 
 constexpr int kPairThreads = 256;
 #ifndef OXHIP_PAIR_R
-#define OXHIP_PAIR_R 2
+#define OXHIP_PAIR_R 4
 #endif
 #ifndef OXHIP_PAIR_IC
 #define OXHIP_PAIR_IC 256
@@ -352,6 +354,21 @@ constexpr int kStage = 512;                         // per-wave LDS staging of h
 // Hits are appended to a per-wave LDS buffer with ballot / prefix-count positions (the wave is its only
 // writer, so no atomic is involved) and flushed to the candidate list with ONE global atomic per flush.
 // A single global counter bumped once per hit serialises at the L2: 291 k hits cost 3 ms that way.
+typedef float pair_f32x2 __attribute__((ext_vector_type(2)));
+
+// host twin of screen_margins / screen_threshold (rrt_device.hpp): the largest binary32 squared distance a pair whose
+// binary64 d2 is <= thr can show, given the magnitude bound m of the coordinates; +inf switches the screen off
+static float host_screen_threshold(double m_all, int dim, double thr) {
+    const double m = m_all * 1.001, u = 0x1p-24;
+    if (!(m < 1e15) || !(thr >= 0.0)) return std::numeric_limits<float>::infinity();
+    const double r = std::sqrt(thr);
+    if (!(r < 1e18)) return std::numeric_limits<float>::infinity();
+    const double a2 = 2.0 * (std::sqrt((double)dim) * 4.1 * u * m + 1e-18);
+    const double r_hi = 1.0 + 2.0 * (0x1p-19 + (double)(dim + 2) * u);
+    const double d = (r * (1.0 + 1e-12) + a2) * r_hi * r_hi;
+    return (float)(d * d * (1.0 + 0x1p-20));
+}
+
 struct PairStage {
     uint2* buf;       // this wave's kStage entries in LDS
     uint32_t cnt;     // wave-uniform
@@ -376,34 +393,53 @@ __device__ __forceinline__ void stage_flush(const PrmArgs& a, PairStage& st, uin
 // the vector memory path.  Hits are rare (a few 1e-4 of all pairs): one wave-uniform branch per i.
 template <int DIM, bool DIAG>
 __device__ __forceinline__ void pairs_one_i(const PrmArgs& a, PairStage& st, uint32_t lane, const double (&cj)[kPairR][DIM],
-                                            const uint32_t (&jr)[kPairR], const double (&ci)[DIM], uint32_t i, double thr) {
-    // distance(q_rand, other)^2 (rvss.rs:137-155: sequential sum over k) for the kPairR milestones, the four
-    // independent chains interleaved so that consecutive f64 instructions never depend on each other
-    double acc[kPairR];
+                                            const pair_f32x2 (&cj32)[kPairR / 2][DIM], const uint32_t (&jr)[kPairR], const float (&ci)[DIM],
+                                            uint32_t i, double thr, float thr32, const double* __restrict__ ms) {
+    // binary32 SCREEN of distance(q_rand, other)^2 for the thread's two milestones at once (packed: v_pk_add / v_pk_fma):
+    // a pair whose screened value exceeds thr32 cannot pass the reference's test (screen_threshold, rrt_device.hpp) ...
+    static_assert(kPairR % 2 == 0, "the milestones of a thread share packed registers two by two");
+    pair_f32x2 s[kPairR / 2];
 #pragma unroll
-    for (int r = 0; r < kPairR; ++r) {
-        const double d = cj[r][0] - ci[0];
-        acc[r] = d * d;
+    for (int r2 = 0; r2 < kPairR / 2; ++r2) {
+        const pair_f32x2 e = cj32[r2][0] - ci[0];
+        s[r2] = e * e;
     }
 #pragma unroll
     for (int k = 1; k < DIM; ++k) {
-        double d[kPairR];
 #pragma unroll
-        for (int r = 0; r < kPairR; ++r) d[r] = cj[r][k] - ci[k];
-#pragma unroll
-        for (int r = 0; r < kPairR; ++r) d[r] = d[r] * d[r];
-#pragma unroll
-        for (int r = 0; r < kPairR; ++r) acc[r] = acc[r] + d[r];
+        for (int r2 = 0; r2 < kPairR / 2; ++r2) {
+            const pair_f32x2 e = cj32[r2][k] - ci[k];
+            s[r2] = __builtin_elementwise_fma(e, e, s[r2]);
+        }
     }
     bool h[kPairR];
     bool any = false;
 #pragma unroll
     for (int r = 0; r < kPairR; ++r) {
-        h[r] = acc[r] <= thr;                             // sqrt(d2) < connection_radius, exactly
+        h[r] = !(s[r / 2][r % 2] > thr32);   // "cannot be excluded": a NaN (inf - inf when the screen is switched off) passes
         if (DIAG) h[r] = h[r] && i < jr[r];
         any = any || h[r];
     }
     if (__ballot(any) != 0) {
+        // ... and the few that pass it get the reference's own arithmetic: distance(q_rand, other)^2 in binary64
+        // (rvss.rs:137-155: sequential sum over k), sqrt(d2) < connection_radius decided exactly as d2 <= thr
+        double cif[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) cif[k] = ms[(size_t)i * DIM + k];
+#pragma unroll
+        for (int r = 0; r < kPairR; ++r) {
+            if (h[r]) {
+                const double d0 = cj[r][0] - cif[0];
+                double acc = d0 * d0;
+#pragma unroll
+                for (int k = 1; k < DIM; ++k) {
+                    double d = cj[r][k] - cif[k];
+                    d = d * d;
+                    acc = acc + d;
+                }
+                h[r] = acc <= thr;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < kPairR; ++r) {
             const uint64_t m = __ballot(h[r]);
@@ -418,33 +454,35 @@ __device__ __forceinline__ void pairs_one_i(const PrmArgs& a, PairStage& st, uin
 // (s_load) while the other's arithmetic runs, so the scalar-cache latency never shows.
 template <int DIM, bool DIAG>
 __device__ __forceinline__ void pairs_range(const PrmArgs& a, PairStage& st, uint32_t lane, const double (&cj)[kPairR][DIM],
-                                            const uint32_t (&jr)[kPairR], const double* __restrict__ ms, uint32_t lo,
-                                            uint32_t hi, double thr) {
+                                            const pair_f32x2 (&cj32)[kPairR / 2][DIM], const uint32_t (&jr)[kPairR],
+                                            const double* __restrict__ ms, const float* __restrict__ ms32, uint32_t lo,
+                                            uint32_t hi, double thr, float thr32) {
     if (lo >= hi) return;
-    double ca[DIM], cb[DIM];
+    float ca[DIM], cb[DIM];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) ca[k] = ms[(size_t)lo * DIM + k];
+    for (int k = 0; k < DIM; ++k) ca[k] = ms32[(size_t)lo * DIM + k];
     for (uint32_t i = lo; i < hi; i += 2) {
         // Scalar loads return out of order, so the only wait is "all of them" (lgkmcnt(0)): each set is
         // requested right before the other set's arithmetic and waited for right after it.
         const uint32_t ib = i + 1 < hi ? i + 1 : i;
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) cb[k] = ms[(size_t)ib * DIM + k];
+        for (int k = 0; k < DIM; ++k) cb[k] = ms32[(size_t)ib * DIM + k];
         __builtin_amdgcn_sched_barrier(0);
-        pairs_one_i<DIM, DIAG>(a, st, lane, cj, jr, ca, i, thr);
+        pairs_one_i<DIM, DIAG>(a, st, lane, cj, cj32, jr, ca, i, thr, thr32, ms);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t ia = i + 2 < hi ? i + 2 : i;
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) ca[k] = ms[(size_t)ia * DIM + k];
+        for (int k = 0; k < DIM; ++k) ca[k] = ms32[(size_t)ia * DIM + k];
         __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < hi) pairs_one_i<DIM, DIAG>(a, st, lane, cj, jr, cb, i + 1, thr);
+        if (i + 1 < hi) pairs_one_i<DIM, DIAG>(a, st, lane, cj, cj32, jr, cb, i + 1, thr, thr32, ms);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
 template <int DIM>
-__global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, const double* __restrict__ ms, uint32_t j0,
-                                                                  uint32_t j1, double thr) {
+__global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, const double* __restrict__ ms,
+                                                                  const float* __restrict__ ms32, uint32_t j0, uint32_t j1,
+                                                                  double thr, float thr32) {
     __shared__ uint2 stage[kPairThreads / 64][kStage];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t jb0 = j0 + blockIdx.y * kPairJB;                 // first j of this block
@@ -461,11 +499,16 @@ __global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, cons
 #pragma unroll
         for (int k = 0; k < DIM; ++k) cj[r][k] = jr[r] < jb1 ? ms[(size_t)jr[r] * DIM + k] : __builtin_inf();
     }
+    pair_f32x2 cj32[kPairR / 2][DIM];   // fl32 of the milestones, two per packed register (+inf stays +inf)
+#pragma unroll
+    for (int r2 = 0; r2 < kPairR / 2; ++r2)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) cj32[r2][k] = pair_f32x2{(float)cj[2 * r2][k], (float)cj[2 * r2 + 1][k]};
     PairStage st{stage[tid >> 6], 0u};
     // i below every j of the block: no index test; the rest of the range (the diagonal blocks) tests i < j
     const uint32_t i_mid = i_hi < jb0 ? i_hi : (i_lo > jb0 ? i_lo : jb0);
-    pairs_range<DIM, false>(a, st, lane, cj, jr, ms, i_lo, i_mid, thr);
-    pairs_range<DIM, true>(a, st, lane, cj, jr, ms, i_mid, i_hi, thr);
+    pairs_range<DIM, false>(a, st, lane, cj, cj32, jr, ms, ms32, i_lo, i_mid, thr, thr32);
+    pairs_range<DIM, true>(a, st, lane, cj, cj32, jr, ms, ms32, i_mid, i_hi, thr, thr32);
     stage_flush(a, st, lane);
 }
 
@@ -574,14 +617,27 @@ void launch_prm_sample_spec(const DevParams& p, const PrmArgs& a, const PrmSpec&
     });
 }
 
+__global__ void prm_shadow_kernel(const double* __restrict__ ms, float* __restrict__ ms32, uint64_t first, uint64_t last) {
+    const uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < last) ms32[i] = (float)ms[i];
+}
+
 void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_t j1, double thr, hipStream_t s) {
     if (j1 <= j0 || j1 < 2) return;
+    // fl32 shadow of the new milestones (the older ones have theirs), then the screen threshold: milestones are samples
+    // inside the bounds, so the magnitude bound M of the error model (rrt_device.hpp) is the bounds'
+    const uint64_t first = (uint64_t)j0 * p.dim, last = (uint64_t)j1 * p.dim;
+    hipLaunchKernelGGL(prm_shadow_kernel, dim3((uint32_t)((last - first + 255) / 256)), dim3(256), 0, s, (const double*)a.ms,
+                       a.ms32, first, last);
+    double m = 0.0;
+    for (uint32_t k = 0; k < p.dim; ++k) m = std::fmax(m, std::fmax(std::fabs(p.lo[k]), std::fabs(p.hi[k])));
+    const float thr32 = host_screen_threshold(m, (int)p.dim, thr);
     const uint32_t jblocks = (j1 - j0 + kPairJB - 1) / kPairJB;
     const uint32_t ichunks = (j1 - 1 + kPairIC - 1) / kPairIC;
     dim_dispatch(p.dim, [&](auto d) {
         constexpr int D = decltype(d)::value;
-        hipLaunchKernelGGL(prm_pairs_kernel<D>, dim3(ichunks, jblocks), dim3(kPairThreads), 0, s, a, (const double*)a.ms, j0,
-                           j1, thr);
+        hipLaunchKernelGGL(prm_pairs_kernel<D>, dim3(ichunks, jblocks), dim3(kPairThreads), 0, s, a, (const double*)a.ms,
+                           (const float*)a.ms32, j0, j1, thr, thr32);
     });
 }
 

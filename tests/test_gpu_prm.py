@@ -259,6 +259,30 @@ def test_prm_many_spheres_filter_is_conservative(dim, n_spheres, rmax):
     assert_same_query(g, o)
 
 
+@pytest.mark.parametrize("scale,offset", [(1.0, 1.0e3), (1.0, 1.0e6), (1.0e-12, 0.0), (1.0e18, 0.0), (1.0e60, 0.0)])
+def test_prm_translated_and_scaled_spaces(scale, offset):
+    """the radius search screens pairs in binary32 over an fl32 shadow of the milestones and decides in binary64; far
+    from the origin the screen separates nothing (every pair is rechecked), beyond 1e15 it is switched off, 1e-12 is
+    the subnormal end: the roadmap must not move by a bit"""
+    dim = 3
+    rng = np.random.default_rng(5)
+    centres = rng.uniform(1.0, 9.0, size=(12, dim)) * scale + offset
+    radii = rng.uniform(0.3, 0.9, size=12) * scale
+    lo, hi = 0.0 * scale + offset, 10.0 * scale + offset
+    P = dict(dim=dim, bounds=[(lo, hi)] * dim, radius=1.3 * scale, fraction=0.05, seed=123, stream=9,
+             max_milestones=1500, max_samples=10 ** 9, boxes=[],
+             spheres=[(list(map(float, c)), float(r)) for c, r in zip(centres, radii)])
+    g, o = make_gpu_prm(P), make_oracle_prm(P)
+    s, gc = [0.4 * scale + offset] * dim, [9.6 * scale + offset] * dim
+    g.setup(s, gc, 1.0 * scale)
+    o.setup(s, gc, 1.0 * scale)
+    g.construct_roadmap()
+    o.construct_roadmap(1500)
+    _, goff, gn = assert_same_roadmap(g, o)
+    assert len(gn) > 1500     # a connected-ish roadmap, not a degenerate one
+    assert_same_query(g, o)
+
+
 def test_prm_fully_blocked_space_returns_an_empty_roadmap():
     """no sample is ever valid: construct_roadmap must still return (the reference would run into its timeout)"""
     P = dict(dim=2, bounds=[(0.0, 1.0), (0.0, 1.0)], radius=0.5, fraction=0.05, seed=1, stream=1, max_milestones=50,

@@ -67,18 +67,21 @@ def prm_asm(tmp_path_factory):
 
 
 def test_prm_pair_search_streams_the_i_side_through_scalar_loads(prm_asm):
-    """the design of DESIGN.md section 9: milestones i are wave-uniform scalar operands (s_load), the loop touches
-    neither LDS nor vector memory, nothing spills, and the distance arithmetic is unfused"""
+    """the design of DESIGN.md section 9: milestones i are wave-uniform scalar operands (s_load of the fl32 shadow), the
+    screen is packed binary32 arithmetic, the loop touches neither LDS nor vector memory, nothing spills, and the exact
+    binary64 recheck of the screen's hits is unfused"""
     meta = {k: v for k, v in _kernels(prm_asm).items() if "prm_pairs_kernel" in k}
     assert len(meta) == 8                      # dim 1..8
     for name, m in meta.items():
         assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, name
         assert m["max_flat_workgroup_size"] == 256
-    body = prm_asm.split("prm_pairs_kernelILi6EEEvNS_7PrmArgsEPKdjjd:")[1].split("s_endpgm")[0]
-    assert body.count("s_load_dwordx8") >= 2 and body.count("s_load_dwordx4") >= 2   # two register sets in flight
+    body = prm_asm.split("prm_pairs_kernelILi6EEEvNS_7PrmArgsEPKdPKfjjdf:")[1].split("s_endpgm")[0]
+    assert body.count("s_load_dwordx4") >= 2 and body.count("s_load_dwordx2") >= 2   # 6 floats per i, two register sets in flight
     assert "v_fma_f64" not in body
-    n_mul, n_add = body.count("v_mul_f64"), body.count("v_add_f64")
-    assert n_mul >= 24 and n_add >= 44         # 2 milestones x 6 dims, two loop bodies (plain + diagonal blocks)
+    # 4 milestones per thread = 2 packed registers per coordinate; per i and loop body: 12 subtractions, 2 squares, 10 fmas
+    assert body.count("v_pk_add_f32") >= 40 and body.count("v_pk_fma_f32") >= 36
+    # the recheck: 6 dims of sub / mul / add per hit, unfused (rvss.rs:137-155)
+    assert body.count("v_mul_f64") >= 24 and body.count("v_add_f64") >= 44
     # the i side never goes through LDS: the only LDS traffic is the staging buffer of the (rare) hits
     loop = body.split("sched_barrier")[1]
     assert "ds_read" not in loop.split("s_cbranch")[0]
