@@ -191,7 +191,13 @@ def main():
                                    "steady@10k (trees pre-grown to 10000 nodes, inserts suppressed)" % P,
                        "problems_per_gpu": P, "iterations_per_problem_per_step": args.iters, "tree_nodes": N_NODES,
                        "spheres": 64, "max_distance": 0.5, "goal_bias": 0.05, "parallelism": "problem-parallel x%d" % world,
-                       "kernel": kname},
+                       "kernel": kname,
+                       # what `dtype` means here: every value that enters a result (distances, steer, motion check, tree,
+                       # checksum) is computed in f64 in the reference's evaluation order; the resident_f32 / stream kernels
+                       # additionally SCREEN nearest-neighbour candidates in packed binary32 with a proven error bound and
+                       # fall back to the f64 scan when the screen cannot decide -- bit-identical results
+                       "arithmetic": ("f64 results; packed-f32 candidate screen + f64 decision" if kname in ("resident_f32", "stream")
+                                      else "f64 throughout")},
             # bound "hbm" = the roofline of any design that re-reads the tree per iteration (33.3 M it/s);
             # the resident kernels keep the tree in VGPRs, so frac > 1 and their own bound is VALU issue
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
