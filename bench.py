@@ -13,10 +13,18 @@ check (6 states x 64 spheres) per iteration, nothing skipped but the push.  Inpu
 in HBM before the timed region; problems are sharded across ranks with no data-path collective
 (weak scaling); torch.distributed (RCCL) is used for the barriers and the throughput gather.
 
-One JSON line on rank 0.  `roofline` prices the grow kernel against the HBM roofline with
-ALGORITHMIC bytes (24 B x tree size per iteration); `cpu_baseline` times the CPU
-oracle (our C restatement of oxmpl's loop, kind "port") on a bounded sample of the same
-workload on this host's cores.
+One JSON line on rank 0 (flat objects only: no nested dictionaries inside `roofline` etc.).
+
+`roofline`: the bound that binds the kernel that ran.  The resident kernels never re-read the tree from
+HBM (it lives in the vector register file), so their bound is VALU issue: `peak` is the measured rate of the
+kernel's own screen instruction mix on this chip (tools/valu_mix_bench.hip -> profiles/r2_valu_peak.json),
+`achieved` the kernel's iterations/s from HIP events.  The byte figure SURVEY.md 8(d) defines (24 B x tree
+size per iteration) is kept as `hbm_equivalent_GBps`; for the stream kernel it is the bound itself.
+
+`cpu_baseline` times the CPU oracle (our C restatement of oxmpl's loop, kind "port") on a bounded sample of
+the same workload on this host's cores -- and the run is only accepted if the GPU's per-problem node
+counts, iteration counts and checksums (every iteration folds nearest index, q_new bits and verdict) equal
+the oracle's on that sample, after the grow phase and after the frozen iterations.
 """
 import argparse
 import json
@@ -31,52 +39,108 @@ if ROOT not in sys.path:
 N_NODES = 10000
 BYTES_PER_ITER = N_NODES * 3 * 8          # B(n) = n * d * 8
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
-# measured on this chip with tools/scan_bench.hip: the bare register scan (10,240 nodes, tie detector
-# included, no reduce / resolve) sustains 1.0 us per CU whatever the wave geometry -> 256 CUs
-VALU_SCAN_CEILING_ITS = 258.0e6
-# the binary32-screen kernel (rrt_resident32.hip): 6 VALU instructions per (register row of 64 nodes, query) -- three packed
-# f32 ops per query pair halved, and_or + med3 + min -- over 160 rows, 4 cycles per wave64 instruction, 4 SIMDs per CU,
-# 2.4 GHz, 256 CUs: an instruction-count bound for the scan alone (no reduce, no resolver)
-VALU_SCREEN_CEILING_ITS = 256 * 4 * 2.4e9 / (160 * 6 * 4)
+KNAME = {1: "stream", 2: "resident", 3: "pruned", 4: "resident_f32"}
+ROWS_PER_ITERATION = 10240 // 64          # register rows (64 nodes each) one query is screened against
+CUS = 256
+
+
+def valu_peak(kname):
+    """Measured VALU ceiling of the kernel's scan on this chip, iterations/s, and where it comes from.
+    resident_f32: profiles/r2_valu_peak.json, the bare screen loop (3 packed f32 ops + v_and_or_b32 + v_med3_u32 +
+    v_min_u32 per register row and query; 22 rows, two waves per SIMD as in the kernel) in (row, query) pairs per second,
+    divided by the 160 rows of a 10,240-slot tree.  resident (binary64 scanners): tools/scan_bench.hip, 1.0 us per
+    10k-node scan per CU (profiles/r1_resident)."""
+    if kname == "resident_f32":
+        try:
+            with open(os.path.join(ROOT, "profiles", "r2_valu_peak.json")) as f:
+                d = json.load(f)
+            for e in d["screen"]:
+                if e["mode"] == 0 and e["dim"] == 3 and e["rows"] == 22 and e["waves_per_simd"] == 2:
+                    return e["row_queries_per_s_chip"] / ROWS_PER_ITERATION, \
+                        "profiles/r2_valu_peak.json: screen mode 0, 22 rows, 2 waves/SIMD, / 160 rows per iteration"
+        except (OSError, KeyError, ValueError):
+            pass
+        return None, "profiles/r2_valu_peak.json missing"
+    if kname == "resident":
+        return 258.0e6, "tools/scan_bench.hip: 1.0 us per 10k-node binary64 scan per CU x 256 CUs"
+    return None, None
 
 
 def measured_traffic(kernel_name, iters_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC run (profiles/r1_traffic.json), valid
-    for the profiled shape only (1024 problems x 4096 iterations); None otherwise."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as f:
-            t = json.load(f)[kernel_name]
-        if iters_per_launch * BYTES_PER_ITER == t["algorithmic_bytes_per_launch"]:
-            return t["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+    """HBM bytes per launch from a committed rocprofv3 PMC run of this shape (1024 problems x 4096 iterations);
+    (None, None) for any other shape.  A constant from a file, not a measurement of this run: `traffic_source` says so."""
+    for name in ("r2_traffic.json", "r1_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)[kernel_name]
+            if iters_per_launch * BYTES_PER_ITER == t["algorithmic_bytes_per_launch"]:
+                return t["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE of this shape; not this run)" % name
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
 
 
-def cpu_baseline(sc, seed, threads, iters):
-    """Oracle (kind 'port') on `threads` host cores: `threads` problems grown to 10k nodes
-    (untimed), then `iters` frozen iterations each (timed) -- same per-iteration work as the GPU step."""
+def copy_peak_gbs(torch, device):
+    """device-to-device copy bandwidth of this GPU (read + write bytes per second), the measured counterpart of the
+    8 TB/s vendor figure (SURVEY.md 8(d) asks for both)."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(5):
+        e0.record()
+        b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        best = ms if best is None or ms < best else best
+    del a, b
+    return 2.0 * n / (best * 1e-3) / 1e9
+
+
+def oracle_planners(sc, seed, first_id, count):
     from oracle import oracle_py as orc
     planners = []
-    for p in range(threads):
+    for p in range(count):
         o = orc.OracleRRT(sc["dim"], sc["bounds"], sc["max_distance"], sc["goal_bias"], sc["lvs_fraction"],
-                          N_NODES, False, seed, p)
+                          N_NODES, False, seed, first_id + p)
         o.set_spheres(*sc["spheres"])
         o.setup(sc["start"], sc["goal_centre"], sc["goal_radius"])
         planners.append(o)
+    return orc, planners
+
+
+def cpu_baseline_and_check(sc, seed, first_id, threads, frozen_iters, gpu_after_grow, gpu_after_frozen):
+    """Oracle (kind 'port') on `threads` host cores: `threads` problems grown to 10k nodes (untimed), then `frozen_iters`
+    frozen iterations each (timed) -- the same per-iteration work as the GPU step, and the SAME iterations the GPU ran
+    for those problems: node counts, iteration counts and checksums must agree at both points, or the run is refused."""
+    orc, planners = oracle_planners(sc, seed, first_id, threads)
     orc.solve_many(planners, 10 ** 7, threads=threads)
-    assert all(p.num_nodes == N_NODES for p in planners)
+    for p, o in enumerate(planners):
+        if not (o.num_nodes == N_NODES == int(gpu_after_grow["nodes"][p]) and o.iterations == int(gpu_after_grow["iterations"][p])
+                and o.checksum == int(gpu_after_grow["checksum"][p])):
+            raise SystemExit("bench.py: GPU != oracle after the grow phase, problem %d: refusing to report a number" % p)
     t0 = time.perf_counter()
-    orc.solve_many(planners, iters, freeze=True, threads=threads)
+    orc.solve_many(planners, frozen_iters, freeze=True, threads=threads)
     dt = time.perf_counter() - t0
+    for p, o in enumerate(planners):
+        if not (o.iterations == int(gpu_after_frozen["iterations"][p]) and o.checksum == int(gpu_after_frozen["checksum"][p])
+                and o.num_nodes == int(gpu_after_frozen["nodes"][p])):
+            raise SystemExit("bench.py: GPU != oracle after %d frozen iterations, problem %d: refusing to report a number"
+                             % (frozen_iters, p))
     # the reference is single-threaded per planner: one problem on one core (SURVEY.md 8(d))
+    n1 = min(frozen_iters, 60000)
     t1 = time.perf_counter()
-    orc.solve_many(planners[:1], iters, freeze=True, threads=1)
+    orc.solve_many(planners[:1], n1, freeze=True, threads=1)
     dt1 = time.perf_counter() - t1
-    return planners, dict(value=threads * iters / dt, unit="iterations/s", cores=threads, kind="port",
-                          value_1core=iters / dt1,
-                          sample="%d problems x %d frozen iterations at n=10000 on %d threads "
-                                 "(oracle/rrt_oracle.c, C restatement of rrt.rs:170-225)" % (threads, iters, threads))
+    return dict(value=threads * frozen_iters / dt, unit="iterations/s", cores=threads, kind="port", value_1core=n1 / dt1,
+                sample="%d problems x %d frozen iterations at n=10000 on %d threads (oracle/rrt_oracle.c, C restatement "
+                       "of rrt.rs:170-225); the GPU ran the same iterations of the same problems" % (threads, frozen_iters, threads),
+                verified="GPU node counts, iteration counts and per-iteration checksums == oracle for problems %d..%d after the "
+                         "grow phase and after the frozen iterations" % (first_id, first_id + threads - 1))
 
 
 def main():
@@ -88,9 +152,9 @@ def main():
     ap.add_argument("--strong-total", type=int, default=0,
                     help="strong scaling: this many problems in total, divided over the ranks (SURVEY.md 8(d): 8192)")
     ap.add_argument("--iters", type=int, default=4096, help="RRT iterations per problem per step")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident, 3 resident + pruned scan, 4 resident + binary32 screen")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident (binary64 scanners), 4 resident + binary32 screen")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary stream-kernel measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (stream kernel, all-binary64 resident kernel)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +176,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    import numpy as np
     from oxmpl_amd import capi, scenarios, sharding
 
     sc = scenarios.config2()
@@ -135,8 +198,11 @@ def main():
     assert (c["nodes"] == N_NODES).all()
     grow_iters = int(c["iterations"].sum())
 
-    for _ in range(args.warmup):
+    snap = None   # (frozen iterations per problem, counters) at a point the CPU check can afford to reach
+    for w in range(args.warmup):
         gpu.solve(args.iters, freeze=True)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline and (w + 1) * args.iters <= 400000:
+            snap = ((w + 1) * args.iters, gpu.counts())   # untimed: warm-up
     barrier()
     t0 = time.perf_counter()
     kernel_ms = 0.0
@@ -152,24 +218,50 @@ def main():
     done = int((c2["iterations"] - c["iterations"]).sum())
     assert done == P * args.iters * (args.steps + args.warmup)
     iters_timed = P * args.iters * args.steps
+    kname = KNAME[gpu.last_timing()["kernel"]]
 
-    kname = {1: "stream", 2: "resident", 3: "pruned", 4: "resident_f32"}[gpu.last_timing()["kernel"]]
-    # secondary (rank 0, N=1 only): the HBM-streaming kernel on the same workload, 2 steps
-    secondary = None
-    if world == 1 and not args.no_secondary and kname != "stream":
+    def side_run(kernel, steps=2):
+        """the same workload through another kernel kind (rank 0, N = 1 only): grow, one warm-up step, `steps` timed"""
         g2 = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id,
-                                  device=local_rank, kernel=capi.KERNEL_STREAM)
+                                  device=local_rank, kernel=kernel)
         g2.solve(10 ** 7)
         g2.solve(args.iters, freeze=True)
         ms2 = 0.0
-        for _ in range(2):
+        for _ in range(steps):
             g2.solve(args.iters, freeze=True)
             ms2 += g2.last_timing()["kernel_ms"]
-        ach2 = P * args.iters * BYTES_PER_ITER / (ms2 / 2 * 1e-3) / 1e9
-        secondary = {"kernel": "stream", "iterations_per_s": P * args.iters / (ms2 / 2 * 1e-3), "kernel_avg_ms": ms2 / 2,
-                     "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": ach2 / HBM_PEAK_GBS, "traffic": measured_traffic("stream", P * args.iters)}}
+        cc = g2.counts()
         g2.close()
+        # same problems, same streams: after the same number of iterations the checksums must equal the main run's
+        same = bool((cc["checksum"] == c2["checksum"]).all()) if (1 + steps) == (args.steps + args.warmup) else None
+        return ms2 / steps, same
+
+    secondary_stream = secondary_f64 = None
+    copy_gbs = None
+    if world == 1 and not args.no_secondary:
+        copy_gbs = copy_peak_gbs(torch, torch.device("cuda", local_rank))
+        if kname != "stream":
+            ms, same = side_run(capi.KERNEL_STREAM)
+            ach = P * args.iters * BYTES_PER_ITER / (ms * 1e-3) / 1e9
+            tr, src = measured_traffic("stream", P * args.iters)
+            secondary_stream = {"kernel": "stream", "iterations_per_s": P * args.iters / (ms * 1e-3), "kernel_avg_ms": ms,
+                                "bound": "hbm", "algorithmic_GBps": ach, "frac_of_vendor_peak_algorithmic": ach / HBM_PEAK_GBS,
+                                "traffic": tr, "traffic_source": src,
+                                # what the kernel really moves: the fl32 shadow (0.5 x algorithmic) + winners; at 1024 problems
+                                # the 126 MB shadow fits the 256 MB Infinity Cache, so this rate is MALL-served, not HBM
+                                "moved_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None,
+                                "served_from": "Infinity Cache (126 MB shadow < 256 MB MALL) -- not an HBM figure",
+                                "checksums_equal_main_run": same}
+        if kname != "resident":
+            try:
+                ms, same = side_run(capi.KERNEL_RESIDENT)
+                pk, pk_src = valu_peak("resident")
+                secondary_f64 = {"kernel": "resident (binary64 scanners: no binary32 anywhere)", "dtype": "f64",
+                                 "iterations_per_s": P * args.iters / (ms * 1e-3), "kernel_avg_ms": ms, "bound": "valu",
+                                 "peak_iterations_per_s": pk, "frac": P * args.iters / (ms * 1e-3) / pk, "peak_source": pk_src,
+                                 "checksums_equal_main_run": same}
+            except capi.OxhipError:
+                secondary_f64 = None
 
     # RCCL all-gather over xGMI (nccl backend): throughput report only, no data-path collective
     allst = sharding.gather_stats([dt, float(iters_timed), kernel_ms, float(launches), float(grow_iters), grow_s,
@@ -180,7 +272,24 @@ def main():
         t_max, value = agg["t_max"], agg["value"]
         avg_launch_ms = float(allst[0, 2] / allst[0, 3])
         iters_per_launch = P * args.iters
-        achieved = iters_per_launch * BYTES_PER_ITER / (avg_launch_ms * 1e-3) / 1e9
+        its = iters_per_launch / (avg_launch_ms * 1e-3)
+        hbm_equiv = its * BYTES_PER_ITER / 1e9
+        traffic, traffic_src = measured_traffic(kname, iters_per_launch)
+        if kname == "stream":
+            roofline = {"bound": "hbm", "achieved": hbm_equiv, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_equiv / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_ms": avg_launch_ms,
+                        "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER}
+        else:
+            peak, peak_src = valu_peak(kname)
+            roofline = {"bound": "valu", "achieved": its, "peak": peak, "unit": "iterations/s",
+                        "frac": (its / peak) if peak else None, "peak_source": peak_src,
+                        "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_ms": avg_launch_ms,
+                        "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER,
+                        # SURVEY.md 8(d)'s byte model, for reference: a design that re-read the tree would need this HBM rate
+                        "hbm_equivalent_GBps": hbm_equiv, "hbm_equivalent_over_vendor_peak": hbm_equiv / HBM_PEAK_GBS,
+                        "hbm_vendor_peak_GBps": HBM_PEAK_GBS, "hbm_copy_peak_GBps": copy_gbs}
+        per_rank_its = (allst[:, 1] / allst[:, 0]).tolist()
+        rounds = -(-P // CUS)
         out = {
             "metric": "RRT iterations/sec (batched problems), R^3 10k-node tree, 64-sphere field",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -192,32 +301,41 @@ def main():
                        "problems_per_gpu": P, "iterations_per_problem_per_step": args.iters, "tree_nodes": N_NODES,
                        "spheres": 64, "max_distance": 0.5, "goal_bias": 0.05, "parallelism": "problem-parallel x%d" % world,
                        "kernel": kname,
+                       # one workgroup (= one problem) per CU at a time: P problems run in ceil(P / 256) rounds
+                       "workgroup_rounds": rounds, "last_round_fill": (P - (rounds - 1) * CUS) / CUS,
                        # what `dtype` means here: every value that enters a result (distances, steer, motion check, tree,
                        # checksum) is computed in f64 in the reference's evaluation order; the resident_f32 / stream kernels
                        # additionally SCREEN nearest-neighbour candidates in packed binary32 with a proven error bound and
                        # fall back to the f64 scan when the screen cannot decide -- bit-identical results
                        "arithmetic": ("f64 results; packed-f32 candidate screen + f64 decision" if kname in ("resident_f32", "stream")
                                       else "f64 throughout")},
-            # bound "hbm" = the roofline of any design that re-reads the tree per iteration (33.3 M it/s);
-            # the resident kernels keep the tree in VGPRs, so frac > 1 and their own bound is VALU issue
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(kname, iters_per_launch),
-                         "kernel_avg_ms": avg_launch_ms, "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER,
-                         "valu": ({"bound": "packed-f32 screen, VALU instruction count (bench.py)", "peak_iterations_per_s": VALU_SCREEN_CEILING_ITS,
-                                   "frac": (iters_per_launch / (avg_launch_ms * 1e-3)) / VALU_SCREEN_CEILING_ITS}
-                                  if kname == "resident_f32" else
-                                  {"bound": "f64-valu scan (tools/scan_bench.hip, measured)", "peak_iterations_per_s": VALU_SCAN_CEILING_ITS,
-                                   "frac": (iters_per_launch / (avg_launch_ms * 1e-3)) / VALU_SCAN_CEILING_ITS})},
+            "roofline": roofline,
             "grow": {"iterations": float(allst[:, 4].sum()), "wall_s": float(allst[:, 5].max()),
                      "iterations_per_s": float(allst[:, 4].sum() / allst[:, 5].max()),
                      "kernel_ms_rank0": float(allst[0, 6])},
+            "per_rank": {"iterations_per_s_min": min(per_rank_its), "iterations_per_s_max": max(per_rank_its),
+                         "step_time_skew": float(allst[:, 0].max() / allst[:, 0].min())},
         }
-        if secondary is not None:
-            out["secondary"] = secondary
+        if copy_gbs is not None:
+            out["hbm_copy_peak_GBps"] = copy_gbs
+        if secondary_stream is not None:
+            if copy_gbs and secondary_stream["moved_GBps"]:
+                secondary_stream["moved_over_copy_peak"] = secondary_stream["moved_GBps"] / copy_gbs
+                secondary_stream["moved_over_vendor_peak"] = secondary_stream["moved_GBps"] / HBM_PEAK_GBS
+            out["secondary"] = secondary_stream
+        if secondary_f64 is not None:
+            out["secondary_f64"] = secondary_f64
         if not args.no_cpu_baseline and world == 1:  # the contract: rank 0, N = 1 only
-            threads = min(os.cpu_count() or 1, 16)
-            planners, base = cpu_baseline(sc, seed, threads, 60000)   # ~25 s of CPU work on 16 threads
-            out["cpu_baseline"] = base
+            threads = min(os.cpu_count() or 1, 16, P)
+            frozen = args.iters * (args.steps + args.warmup)
+            if frozen <= 400000:
+                point = (frozen, c2)       # the whole frozen run, as timed
+            elif snap is not None:
+                point = snap               # a long run: compare at the last affordable warm-up boundary
+            else:
+                raise SystemExit("bench.py: %d frozen iterations per problem are too many for the CPU check and there is no "
+                                 "warm-up boundary to compare at; use --warmup >= 1 or --no-cpu-baseline" % frozen)
+            out["cpu_baseline"] = cpu_baseline_and_check(sc, seed, first_id, threads, point[0], c, point[1])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

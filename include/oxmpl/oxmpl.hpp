@@ -207,6 +207,9 @@ class RRT {
     // Planner::solve (rrt.rs:158-227)
     Result<base::Path, base::PlanningError> solve(std::chrono::duration<double> timeout) {
         if (!batch_ || last_status_ != OXHIP_OK) return base::PlanningError::PlannerUninitialised;  // rrt.rs:160-163
+        // rrt.rs:172-174: `start_time.elapsed() > timeout` holds at the first check for a zero Duration (Rust's Duration has
+        // no negative values or NaN: both are treated like zero here)
+        if (!(timeout.count() > 0.0)) return base::PlanningError::Timeout;
         int32_t st = OXHIP_ERR_NO_SOLUTION_FOUND;
         last_status_ = oxhip_rrt_batch_solve(batch_, 1ull << 40, timeout.count(), 0, &st);
         if (last_status_ == OXHIP_ERR_PLANNER_UNINITIALISED) return base::PlanningError::PlannerUninitialised;

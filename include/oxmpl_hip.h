@@ -74,7 +74,7 @@ typedef enum oxhip_kernel_kind {
     OXHIP_KERNEL_AUTO = 0,      /* resident (binary32 screen) when the tree fits the register file, else streaming */
     OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
     OXHIP_KERNEL_RESIDENT = 2,  /* tree held in the workgroup's vector registers, every node scanned */
-    OXHIP_KERNEL_PRUNED = 3,    /* resident + spatially sorted rows with bounding boxes: exact pruned scan */
+    OXHIP_KERNEL_PRUNED = 3,    /* experiment, only in builds made with WITH_PRUNED=1 (else OXHIP_ERR_BAD_ARG): resident + box-pruned scan */
     OXHIP_KERNEL_RESIDENT_F32 = 4 /* resident, the scanners screen in packed binary32 and the resolver decides in binary64
                                      from the binary64 nodes: same results bit for bit (rrt_resident32.hip) */
 } oxhip_kernel_kind;
@@ -148,7 +148,11 @@ int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const dou
 
 /* Planner::solve (rrt.rs:158-227).  Runs every unfinished problem for at most max_iterations
  * further iterations (one iteration = one pass of rrt.rs:170-225).  timeout_s bounds wall time
- * (checked between kernel chunks; <= 0 or inf = none).  freeze != 0 suppresses inserts
+ * (checked between kernel launches of at most 2048 iterations; 0 or +inf = none; NaN or negative =
+ * OXHIP_ERR_BAD_ARG).  The planner mirrors above this ABI map the reference's `solve(Duration::ZERO)`
+ * to PlanningError::Timeout themselves (rrt.rs:172-174 fails its first clock check).  Without a timeout
+ * the budget is still cut into launches of 65,536 iterations so the host can see every problem stop.
+ * freeze != 0 suppresses inserts
  * ("steady" measurement mode: every nearest-neighbour scan sees the same tree).
  * status_out[P] (may be NULL): OXHIP_OK if the problem has a goal node, else
  * OXHIP_ERR_NO_SOLUTION_FOUND / OXHIP_ERR_TIMEOUT.  Calling solve again continues the same

@@ -22,6 +22,13 @@
 
 using namespace oxhip;
 
+#ifndef OXHIP_WITH_PRUNED   // the pruned-scan experiment is left out of the product build (Makefile: WITH_PRUNED=1)
+namespace oxhip {
+bool pruned_supported(uint32_t, uint32_t) { return false; }
+void launch_rrt_pruned(const DevParams&, hipStream_t) {}
+}
+#endif
+
 struct oxhip_rrt_batch {
     oxhip_rrt_config cfg{};
     DevParams dp{};
@@ -187,7 +194,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
              : resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_PRUNED && !pruned_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
-        return fail(OXHIP_ERR_BAD_ARG, "resident (pruned) kernel does not support this (dim, max_nodes)");
+        return fail(OXHIP_ERR_BAD_ARG, "resident (pruned) kernel: not in this build (make WITH_PRUNED=1) or no instantiation for this (dim, max_nodes)");
     }
     if (kind == OXHIP_KERNEL_RESIDENT_F32 && !resident32_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
@@ -432,11 +439,16 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
     if (st != OXHIP_OK) return st;
     if (b->cfg.planner != OXHIP_PLANNER_RRT && freeze) return fail(OXHIP_ERR_BAD_ARG, "freeze is for the RRT planner");
     if ((st = refresh_filter(b)) != OXHIP_OK) return st;
+    if (std::isnan(timeout_s) || timeout_s < 0.0)   // Duration cannot be negative; from_secs_f32 (oxmpl-py rrt.rs:112) panics on both
+        return fail(OXHIP_ERR_BAD_ARG, "timeout_s is NaN or negative (0 or +inf = no wall-clock limit)");
     const bool has_timeout = timeout_s > 0.0 && std::isfinite(timeout_s);
     const auto t0 = std::chrono::steady_clock::now();
-    // with a timeout the budget is cut into chunks so the host clock is consulted in between
-    // a launch's budget stays below 2^31 (the pipeline kernel counts queries in 32 bits)
-    const uint64_t chunk = has_timeout ? 2048 : (max_iterations < (1ull << 30) ? max_iterations : (1ull << 30));
+    // The budget is always cut into bounded launches: the host reads the stop reasons in between, so a problem that can
+    // never finish (start enclosed, huge budget) costs one chunk at a time instead of pinning the GPU for 2^40 iterations,
+    // and with a timeout the host clock is consulted at the same points (rrt.rs:172-174).  Results do not depend on the
+    // cut (a launch resumes from the state array).  A launch's budget stays below 2^31 (32-bit query counters).
+    const uint64_t kChunk = has_timeout ? 2048 : 65536;
+    const uint64_t chunk = max_iterations < kChunk ? max_iterations : kChunk;
     uint64_t remaining = max_iterations;
     b->last_kernel_ms = 0.0;
     b->last_launches = 0;

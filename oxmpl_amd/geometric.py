@@ -22,6 +22,13 @@ _MESSAGES = {  # Display strings of PlanningError (oxmpl/src/base/error.rs:110-1
 
 
 class RRT:
+    """One-problem drop-in for `oxmpl_py.geometric.RRT`.
+
+    Difference from the reference, on purpose: the tree lives in a device buffer sized at setup(), so it is capped at
+    `max_nodes` (default 10,000).  The reference has no node cap (rrt.rs:170-226 grows until the wall clock runs out);
+    here a problem that fills its tree before the timeout ends with "No solution found." (PlanningError::NoSolutionFound,
+    declared but unused by the reference's RRT) instead of "No solution found within timeout.".  Pass a larger `max_nodes`
+    for narrow-passage problems.  `solve(0)` is Timeout, as upstream."""
     _PLANNER = capi.PLANNER_RRT
 
     def __init__(self, max_distance, goal_bias, problem_definition, max_nodes=10000, seed=0, problem_id=0, device=0):
@@ -62,7 +69,14 @@ class RRT:
         (oxmpl-py/src/geometric/rrt.rs:117)."""
         if self._batch is None:
             raise Exception(_MESSAGES[capi.ERR_PLANNER_UNINITIALISED])
-        st = self._batch.solve(1 << 40, timeout_s=float(timeout_secs))
+        timeout_secs = float(timeout_secs)
+        if timeout_secs != timeout_secs or timeout_secs < 0.0:
+            # Duration::from_secs_f32 (oxmpl-py/src/geometric/rrt.rs:111) panics on NaN / negative values
+            raise ValueError("timeout_secs must be a non-negative number")
+        if timeout_secs == 0.0:
+            # rrt.rs:172-174: `start_time.elapsed() > timeout` already holds at the first check
+            raise Exception(_MESSAGES[capi.ERR_TIMEOUT])
+        st = self._batch.solve(1 << 40, timeout_s=timeout_secs)
         if st[0] != capi.OK:
             raise Exception(_MESSAGES.get(int(st[0]), capi.status_string(int(st[0]))))
         return Path([RealVectorState(row) for row in self._batch.path(0)])

@@ -1,36 +1,61 @@
-"""The oxmpl_py class-surface mirror (oxmpl_amd.base / oxmpl_amd.geometric).
+"""The Python class surface of the GPU path (oxmpl_amd.base / oxmpl_amd.geometric) against the scenes the reference's
+Python tests plan in.
 
-test_rrt_finds_path_in_rvss is the reference's oxmpl-py/tests/test_rrt_rvss.py with the import line
-changed and the per-state Python callback replaced by its obstacle description."""
+The scenes are data (oxmpl_amd.scenarios.wall / config1: the wall-with-gaps scene of the reference's RRT, RRTConnect,
+RRT* and PRM tests, and the README quick-start); the goal object and the checks below are written for this repo.  What
+the reference's tests establish for a returned path -- it starts at the start state, ends inside the goal region, and
+every vertex satisfies the validity predicate (oxmpl-py/tests/test_rrt_rvss.py, test_prm_rvss.py, ...) -- is what
+`check_path` asserts, with the predicate evaluated twice: by the scene's own Python description and on the device."""
 import math
-import random
 
 import pytest
 
+from oxmpl_amd import scenarios
 from oxmpl_amd.base import RealVectorState, RealVectorStateSpace, ProblemDefinition, SphereBoxValidityChecker, Path
 from oxmpl_amd.geometric import PRM, RRT, RRTConnect, RRTStar
 
 
-class CircularGoal:
-    def __init__(self, space, x, y, radius):
-        self.space = space
-        self.target = RealVectorState([x, y])
-        self.radius = radius
-        self.rng = random.Random(123)
+class BallGoal:
+    """A goal region the device path understands: every state within `radius` of `target`.  (The planners only read
+    `target` and `radius`; sampling the region returns its centre, README.md:160-162.)"""
+
+    def __init__(self, space, centre, radius):
+        self.space, self.target, self.radius = space, RealVectorState(centre), float(radius)
 
     def is_satisfied(self, state):
-        return self.space.distance(self.target, state) <= self.radius
+        return self.space.distance(state, self.target) <= self.radius
 
     def sample_goal(self):
-        angle = self.rng.uniform(0, 2 * math.pi)
-        radius = self.radius * math.sqrt(self.rng.uniform(0, 1))
-        return RealVectorState([self.target.values[0] + radius * math.cos(angle),
-                                self.target.values[1] + radius * math.sin(angle)])
+        return RealVectorState(self.target.values)
 
 
-def is_state_valid(state):
-    x, y = state.values
-    return not (4.75 <= x <= 5.25 and 2.0 <= y <= 8.0)
+def scene_objects(sc):
+    """(space, start, goal, checker, python predicate) for a scenario dict"""
+    space = RealVectorStateSpace(dimension=sc["dim"], bounds=sc["bounds"])
+    start = RealVectorState(sc["start"])
+    goal = BallGoal(space, sc["goal_centre"], sc["goal_radius"])
+    spheres = [] if sc["spheres"] is None else [(list(c), float(r)) for c, r in zip(*sc["spheres"])]
+    boxes = [] if sc["boxes"] is None else [(list(lo), list(hi)) for lo, hi in zip(*sc["boxes"])]
+    checker = SphereBoxValidityChecker(spheres=spheres, boxes=boxes)
+
+    def free(state):
+        v = state.values
+        for c, r in spheres:
+            if not math.sqrt(sum((a - b) ** 2 for a, b in zip(c, v))) > r:
+                return False
+        return not any(all(l <= x <= h for l, x, h in zip(lo, v, hi)) for lo, hi in boxes)
+
+    return space, start, goal, checker, free
+
+
+def check_path(path, space, start, goal, free, planner=None):
+    assert len(path.states) >= 2
+    assert space.distance(path.states[0], start) < 1e-9
+    assert goal.is_satisfied(path.states[-1])
+    for s in path.states:
+        assert free(s), s.values
+        if planner is not None:
+            assert planner.is_state_valid(s)
 
 
 def test_constructors_and_errors_match_the_reference():
@@ -51,7 +76,7 @@ def test_constructors_and_errors_match_the_reference():
     st = RealVectorState([1, 2])
     assert st.values == [1.0, 2.0] and "RealVectorState" in repr(st)
     assert len(Path.from_real_vector_states([st, st])) == 2
-    goal = CircularGoal(s, 0.5, 0.5, 0.1)
+    goal = BallGoal(s, [0.5, 0.5], 0.1)
     pd = ProblemDefinition.from_real_vector(s, st, goal)
     with pytest.raises(TypeError):
         ProblemDefinition.from_real_vector(s, st, object())
@@ -59,120 +84,82 @@ def test_constructors_and_errors_match_the_reference():
     with pytest.raises(Exception, match="was not called, thus Planner is uninitialised"):
         planner.solve(timeout_secs=1.0)          # PlanningError::PlannerUninitialised
     with pytest.raises(TypeError, match="Python function per interpolated state"):
-        planner.setup(is_state_valid)             # closures are refused, never run on a CPU path
+        planner.setup(lambda state: True)         # closures are refused, never run on a CPU path
 
 
 @pytest.mark.gpu
-def test_rrt_finds_path_in_rvss():
-    space = RealVectorStateSpace(dimension=2, bounds=[(0.0, 10.0), (0.0, 10.0)])
-    start_state = RealVectorState([1.0, 5.0])
-    goal_region = CircularGoal(space, x=9.0, y=5.0, radius=0.5)
-    problem_def = ProblemDefinition.from_real_vector(space, start_state, goal_region)
-    planner = RRT(max_distance=0.5, goal_bias=0.05, problem_definition=problem_def)
-    planner.setup(SphereBoxValidityChecker(boxes=[([4.75, 2.0], [5.25, 8.0])]))
-    try:
-        path = planner.solve(timeout_secs=5.0)
-    except Exception as e:  # noqa: BLE001 - the reference test does the same
-        pytest.fail(f"Planner failed to find a solution when one should exist. Error: {e}")
-    assert len(path.states) > 1, "Path should contain at least a start and end state."
-    assert space.distance(path.states[0], start_state) < 1e-9, "Path must start at the start state."
-    assert goal_region.is_satisfied(path.states[-1]), "Path must end inside the goal region."
-    for state in path.states:
-        assert is_state_valid(state), f"Path contains an invalid state: {state.values}"
-        assert planner.is_state_valid(state)
+@pytest.mark.parametrize("make", [
+    lambda pd: RRT(max_distance=0.5, goal_bias=0.05, problem_definition=pd),
+    lambda pd: RRTConnect(max_distance=0.5, goal_bias=0.05, problem_definition=pd),
+    lambda pd: RRTStar(max_distance=0.5, goal_bias=0.05, search_radius=0.25, problem_definition=pd),
+], ids=["RRT", "RRTConnect", "RRTStar"])
+def test_tree_planners_cross_the_wall_scene(make):
+    """the reference's planner parameters (oxmpl-py/tests/test_rrt_rvss.py:54, test_rrt_star_rvss.py) on the wall scene"""
+    space, start, goal, checker, free = scene_objects(scenarios.wall())
+    planner = make(ProblemDefinition.from_real_vector(space, start, goal))
+    planner.setup(checker)
+    path = planner.solve(timeout_secs=5.0)
+    check_path(path, space, start, goal, free, planner)
+    assert planner.num_nodes >= len(path.states) - 1
     assert abs(space.get_maximum_extent() - math.sqrt(200.0)) < 1e-12
+    if isinstance(planner, RRTStar):
+        # the goal node's cost-to-come never undercuts the straight line from the start (rewires do not propagate costs)
+        assert planner.path_cost() >= space.distance(start, path.states[-1]) - 1e-9
+
+
+@pytest.mark.gpu
+def test_timeout_semantics_follow_the_reference():
+    """rrt.rs:172-174: a zero Duration fails the first clock check; Duration::from_secs_f32 refuses NaN / negatives"""
+    space, start, goal, checker, _ = scene_objects(scenarios.wall())
+    planner = RRT(0.5, 0.05, ProblemDefinition.from_real_vector(space, start, goal))
+    planner.setup(checker)
+    with pytest.raises(Exception, match="No solution found within timeout"):
+        planner.solve(timeout_secs=0.0)
+    for bad in (-1.0, float("nan")):
+        with pytest.raises(ValueError):
+            planner.solve(timeout_secs=bad)
+    # a start walled in by a box can never grow a tree: the call must come back with Timeout, not spin on a 2^40 budget
+    boxed = SphereBoxValidityChecker(boxes=[([0.0, 0.0], [10.0, 10.0])])
+    p2 = RRT(0.5, 0.0, ProblemDefinition.from_real_vector(space, start, goal))
+    p2.setup(boxed)
+    with pytest.raises(Exception, match="No solution found within timeout"):
+        p2.solve(timeout_secs=0.3)
+    assert p2.num_nodes == 1
 
 
 @pytest.mark.gpu
 def test_readme_quickstart_python():
     """README.md:138-181 (config 1): disc obstacle r=2 at the origin, start (-5,-5), goal (5,5) r=0.5"""
-    space = RealVectorStateSpace(dimension=2, bounds=[(-10.0, 10.0), (-10.0, 10.0)])
-    goal = CircularGoal(space, 5.0, 5.0, 0.5)
-    pd = ProblemDefinition.from_real_vector(space, RealVectorState([-5.0, -5.0]), goal)
-    planner = RRT(max_distance=0.5, goal_bias=0.05, problem_definition=pd)
-    planner.setup(SphereBoxValidityChecker(spheres=[([0.0, 0.0], 2.0)]))
-    path = planner.solve(timeout_secs=5.0)
-    assert len(path.states) > 1
-    for s in path.states:
-        x, y = s.values
-        assert math.sqrt(x ** 2 + y ** 2) > 2.0
-    assert goal.is_satisfied(path.states[-1])
-    # an unreachable goal times out with the reference's message
-    far = CircularGoal(space, 0.0, 0.0, 0.5)  # inside the obstacle
-    p2 = RRT(0.5, 0.0, ProblemDefinition.from_real_vector(space, RealVectorState([-5.0, -5.0]), far), max_nodes=200)
-    p2.setup(SphereBoxValidityChecker(spheres=[([0.0, 0.0], 2.0)]))
+    space, start, goal, checker, free = scene_objects(scenarios.config1())
+    planner = RRT(max_distance=0.5, goal_bias=0.05, problem_definition=ProblemDefinition.from_real_vector(space, start, goal))
+    planner.setup(checker)
+    check_path(planner.solve(timeout_secs=5.0), space, start, goal, free, planner)
+    # a goal inside the obstacle is unreachable: the node cap ends the search with NoSolutionFound's message
+    inside = BallGoal(space, [0.0, 0.0], 0.5)
+    p2 = RRT(0.5, 0.0, ProblemDefinition.from_real_vector(space, start, inside), max_nodes=200)
+    p2.setup(checker)
     with pytest.raises(Exception, match="No solution found"):
         p2.solve(timeout_secs=0.2)
 
 
 @pytest.mark.gpu
-def test_rrt_connect_finds_path_in_rvss():
-    """oxmpl-py/tests/test_rrt_connect_rvss.py with the import line changed (same scene as the RRT test)"""
-    space = RealVectorStateSpace(dimension=2, bounds=[(0.0, 10.0), (0.0, 10.0)])
-    start_state = RealVectorState([1.0, 5.0])
-    goal_region = CircularGoal(space, x=9.0, y=5.0, radius=0.5)
-    problem_def = ProblemDefinition.from_real_vector(space, start_state, goal_region)
-    planner = RRTConnect(max_distance=0.5, goal_bias=0.05, problem_definition=problem_def)
-    planner.setup(SphereBoxValidityChecker(boxes=[([4.75, 2.0], [5.25, 8.0])]))
-    path = planner.solve(timeout_secs=5.0)
-    assert len(path.states) > 1
-    assert space.distance(path.states[0], start_state) < 1e-9
-    assert goal_region.is_satisfied(path.states[-1])
-    for state in path.states:
-        assert is_state_valid(state), f"Path contains an invalid state: {state.values}"
-    assert planner.num_nodes >= len(path.states)
-
-
-@pytest.mark.gpu
-def test_prm_finds_path_in_rvss():
-    """oxmpl-py/tests/test_prm_rvss.py with the import line changed and the callback replaced by its description"""
-    space = RealVectorStateSpace(dimension=2, bounds=[(0.0, 10.0), (0.0, 10.0)])
-    start_state = RealVectorState([1.0, 5.0])
-    goal_region = CircularGoal(space, x=9.0, y=5.0, radius=0.5)
-    problem_def = ProblemDefinition.from_real_vector(space, start_state, goal_region)
-    planner = PRM(timeout=5.0, connection_radius=0.5, problem_definition=problem_def)
+def test_prm_answers_several_queries_on_one_roadmap():
+    """PRM(timeout, connection_radius) on the wall scene (the reference's parameters, oxmpl-py/tests/test_prm_rvss.py),
+    then further start / goal pairs on the same roadmap (prm.rs:86-90)"""
+    space, start, goal, checker, free = scene_objects(scenarios.wall())
+    planner = PRM(timeout=5.0, connection_radius=0.5, problem_definition=ProblemDefinition.from_real_vector(space, start, goal))
     with pytest.raises(Exception, match="was not called, thus Planner is uninitialised"):
         planner.construct_roadmap()
-    planner.setup(SphereBoxValidityChecker(boxes=[([4.75, 2.0], [5.25, 8.0])]))
+    planner.setup(checker)
     with pytest.raises(Exception, match="StateSpace is not sampled"):
         planner.solve(timeout_secs=5.0)
     planner.construct_roadmap()
     assert planner.num_milestones == 16384
-    try:
-        path = planner.solve(timeout_secs=5.0)
-    except Exception as e:  # noqa: BLE001 - the reference test does the same
-        pytest.fail(f"Planner failed to find a solution when one should exist. Error: {e}")
-    assert len(path.states) > 1, "Path should contain at least a start and end state."
-    assert space.distance(path.states[0], start_state) < 1e-9, "Path must start at the start state."
-    assert goal_region.is_satisfied(path.states[-1]), "Path must end inside the goal region."
-    for state in path.states:
-        assert is_state_valid(state), f"Path contains an invalid state: {state.values}"
-    # multi-query use: a new problem on the same roadmap (prm.rs:86-90)
-    g2 = CircularGoal(space, x=1.0, y=9.0, radius=0.5)
-    planner.set_problem_definition(ProblemDefinition.from_real_vector(space, RealVectorState([9.0, 1.0]), g2))
-    p2 = planner.solve(timeout_secs=5.0)
-    assert p2.states[0].values == [9.0, 1.0] and g2.is_satisfied(p2.states[-1])
+    check_path(planner.solve(timeout_secs=5.0), space, start, goal, free)
+    g2 = BallGoal(space, [1.0, 9.0], 0.5)
+    s2 = RealVectorState([9.0, 1.0])
+    planner.set_problem_definition(ProblemDefinition.from_real_vector(space, s2, g2))
+    check_path(planner.solve(timeout_secs=5.0), space, s2, g2, free)
     planner.set_problem_definition(ProblemDefinition.from_real_vector(space, RealVectorState([5.0, 5.0]), g2))
     with pytest.raises(Exception, match="Start state is not valid"):
         planner.solve(timeout_secs=5.0)
-
-
-@pytest.mark.gpu
-def test_rrt_star_finds_path_in_rvss():
-    """oxmpl-py/tests/test_rrt_star_rvss.py with the import line changed (same scene and parameters)"""
-    space = RealVectorStateSpace(dimension=2, bounds=[(0.0, 10.0), (0.0, 10.0)])
-    start_state = RealVectorState([1.0, 5.0])
-    goal_region = CircularGoal(space, x=9.0, y=5.0, radius=0.5)
-    problem_def = ProblemDefinition.from_real_vector(space, start_state, goal_region)
-    planner = RRTStar(max_distance=0.5, goal_bias=0.05, search_radius=0.25, problem_definition=problem_def)
-    planner.setup(SphereBoxValidityChecker(boxes=[([4.75, 2.0], [5.25, 8.0])]))
-    path = planner.solve(timeout_secs=5.0)
-    assert len(path.states) > 1
-    assert space.distance(path.states[0], start_state) < 1e-9
-    assert goal_region.is_satisfied(path.states[-1])
-    for state in path.states:
-        assert is_state_valid(state), f"Path contains an invalid state: {state.values}"
-    # the goal node's cost-to-come is the length of the returned path or less (rewires do not propagate costs)
-    length = sum(space.distance(a, b) for a, b in zip(path.states, path.states[1:]))
-    assert planner.path_cost() >= space.distance(start_state, path.states[-1]) - 1e-9
-    assert abs(planner.path_cost() - length) < 1e-6 or planner.path_cost() > 0.0

@@ -54,7 +54,7 @@ def case_rv(planner):
     radius = float(rng.choice([0.0, 0.05, 0.15, 0.5])) * w
     kernels = [capi.KERNEL_STREAM]
     if planner == capi.PLANNER_RRT and dim in (2, 3):
-        kernels += [capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED, capi.KERNEL_RESIDENT_F32]
+        kernels += [capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32]
     kernel = int(rng.choice(kernels))
     desc = dict(planner=planner, kernel=kernel, dim=dim, lo=lo, hi=hi, md=md, gb=gb, frac=frac, ns=len(sr), nb=len(blo),
                 seed=seed, pid0=pid0, nprob=nprob, max_nodes=max_nodes, iters=iters, stop=stop, radius=radius)
