@@ -221,19 +221,23 @@ def main():
     kname = KNAME[gpu.last_timing()["kernel"]]
 
     def side_run(kernel, steps=2):
-        """the same workload through another kernel kind (rank 0, N = 1 only): grow, one warm-up step, `steps` timed"""
+        """the same workload through another kernel kind (rank 0, N = 1 only)"""
         g2 = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id,
                                   device=local_rank, kernel=kernel)
         g2.solve(10 ** 7)
-        g2.solve(args.iters, freeze=True)
+        total = args.steps + args.warmup          # as many frozen steps as the main run, the last `steps` of them timed
+        steps = min(steps, total)
         ms2 = 0.0
-        for _ in range(steps):
+        for i in range(total):
             g2.solve(args.iters, freeze=True)
-            ms2 += g2.last_timing()["kernel_ms"]
+            if i >= total - steps:
+                ms2 += g2.last_timing()["kernel_ms"]
         cc = g2.counts()
         g2.close()
-        # same problems, same streams: after the same number of iterations the checksums must equal the main run's
-        same = bool((cc["checksum"] == c2["checksum"]).all()) if (1 + steps) == (args.steps + args.warmup) else None
+        # same problems, same streams, same number of iterations: every checksum must equal the main run's
+        same = bool((cc["checksum"] == c2["checksum"]).all() and (cc["iterations"] == c2["iterations"]).all())
+        if not same:
+            raise SystemExit("bench.py: kernel kind %d disagrees with the main run's checksums: refusing to report" % kernel)
         return ms2 / steps, same
 
     secondary_stream = secondary_f64 = None
