@@ -75,8 +75,11 @@ typedef enum oxhip_kernel_kind {
     OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
     OXHIP_KERNEL_RESIDENT = 2,  /* tree held in the workgroup's vector registers, every node scanned */
     OXHIP_KERNEL_PRUNED = 3,    /* experiment, only in builds made with WITH_PRUNED=1 (else OXHIP_ERR_BAD_ARG): resident + box-pruned scan */
-    OXHIP_KERNEL_RESIDENT_F32 = 4 /* resident, the scanners screen in packed binary32 and the resolver decides in binary64
+    OXHIP_KERNEL_RESIDENT_F32 = 4, /* resident, the scanners screen in packed binary32 and the resolver decides in binary64
                                      from the binary64 nodes: same results bit for bit (rrt_resident32.hip) */
+    OXHIP_KERNEL_LANES = 5        /* resident + binary32 screen with a lane-per-query resolver: up to 64 iterations are
+                                     resolved side by side and committed as the longest prefix that keeps the reference's
+                                     sequential semantics (rrt_lanes.hip); same results bit for bit */
 } oxhip_kernel_kind;
 
 /* RRT::new(max_distance, goal_bias) (rrt.rs:75-83) + RealVectorStateSpace::new(dim, bounds)

@@ -419,13 +419,16 @@ int orc_rrt_solve(orc_rrt* r, uint64_t max_iterations, int freeze, double timeou
         }
         /* 5. motion check (rrt.rs:211) */
         int ok = check_motion(r, q_near, q_new);
-        uint64_t h = fnv_mix(r->checksum, (uint64_t)nearest);
+        /* checksum (build-defined): digest g of this iteration = FNV-1a fold from the basis of (nearest, bits(q_new), ok);
+         * running value H <- H * P + g (mod 2^64) */
+        uint64_t g = fnv_mix(0xCBF29CE484222325ull, (uint64_t)nearest);
         for (uint32_t k = 0; k < dim; ++k) {
             uint64_t b;
             memcpy(&b, &q_new[k], sizeof b);
-            h = fnv_mix(h, b);
+            g = fnv_mix(g, b);
         }
-        r->checksum = fnv_mix(h, (uint64_t)ok);
+        g = fnv_mix(g, (uint64_t)ok);
+        r->checksum = r->checksum * 0x100000001B3ull + g;
         r->iterations++;
         int hit = 0;
         if (ok) {

@@ -18,7 +18,7 @@ OK, ERR_TIMEOUT, ERR_NO_SOLUTION_FOUND, ERR_PLANNER_UNINITIALISED = 0, 1, 2, 3
 ERR_INVALID_START_STATE, ERR_UNSAMPLED_STATE_SPACE = 4, 5
 ERR_BAD_ARG, ERR_UNBOUNDED, ERR_ZERO_VOLUME, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE = 16, 17, 18, 19, 32, 33
 STOP_NONE, STOP_GOAL, STOP_ITERATIONS, STOP_NODES, STOP_TIMEOUT = -1, 0, 1, 2, 3
-KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT, KERNEL_PRUNED, KERNEL_RESIDENT_F32 = 0, 1, 2, 3, 4
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT, KERNEL_PRUNED, KERNEL_RESIDENT_F32, KERNEL_LANES = 0, 1, 2, 3, 4, 5
 PLANNER_RRT, PLANNER_RRT_CONNECT, PLANNER_RRT_STAR = 0, 1, 2
 SPACE_REAL_VECTOR, SPACE_SE2 = 0, 1
 

@@ -99,7 +99,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_BAD_ARG, "goal_bias outside [0,1] (rand Bernoulli::new would fail)");
     if (!(cfg->max_distance > 0.0) || !std::isfinite(cfg->max_distance))
         return fail(OXHIP_ERR_BAD_ARG, "max_distance must be finite and > 0");
-    if (cfg->kernel > OXHIP_KERNEL_RESIDENT_F32) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
+    if (cfg->kernel > OXHIP_KERNEL_LANES) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
     if (cfg->planner > OXHIP_PLANNER_RRT_STAR) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
     if (cfg->planner != OXHIP_PLANNER_RRT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
         return fail(OXHIP_ERR_BAD_ARG, "RRTConnect / RRT* run on the stream kernel only");
@@ -195,6 +195,10 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (kind == OXHIP_KERNEL_PRUNED && !pruned_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
         return fail(OXHIP_ERR_BAD_ARG, "resident (pruned) kernel: not in this build (make WITH_PRUNED=1) or no instantiation for this (dim, max_nodes)");
+    }
+    if (kind == OXHIP_KERNEL_LANES && !lanes_supported(dim, cap)) {
+        oxhip_rrt_batch_destroy(b);
+        return fail(OXHIP_ERR_BAD_ARG, "resident (lane-per-query) kernel does not support this (dim, max_nodes)");
     }
     if (kind == OXHIP_KERNEL_RESIDENT_F32 && !resident32_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
@@ -463,6 +467,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) launch_rrt_star(b->dp, b->stream);
         else if (b->kernel_kind == OXHIP_KERNEL_PRUNED) launch_rrt_pruned(b->dp, b->stream);
+        else if (b->kernel_kind == OXHIP_KERNEL_LANES) launch_rrt_lanes(b->dp, b->stream);
         else if (b->kernel_kind == OXHIP_KERNEL_RESIDENT_F32) launch_rrt_resident32(b->dp, b->stream);
         else if (b->kernel_kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
         else launch_rrt_stream(b->dp, b->stream);

@@ -561,4 +561,18 @@ __device__ __forceinline__ Exact exact_wave_reduce(Exact v) {
 
 __device__ __forceinline__ uint64_t fnv_mix(uint64_t h, uint64_t v) { return (h ^ v) * kFnvPrime; }
 
+// RRT's running checksum (build-defined; the CPU checker and the golden generator restate it): every iteration
+// has a digest g = FNV-1a fold, from the FNV basis, of (nearest index, bits of q_new[0..dim), verdict), and the run's
+// checksum is the polynomial H <- H * P + g (mod 2^64, P the FNV prime, odd: multiplication by P is a bijection), i.e.
+// H_T = B P^T + sum_t g_t P^(T-1-t): order-sensitive like a chained hash, but a batch of iterations folds in as
+// H * P^m + sum_j g_j * P^(m-1-j) -- one step for a whole wave of queries instead of 5 dependent 64-bit multiplies each.
+__device__ __forceinline__ uint64_t chk_push(uint64_t h, uint64_t g) { return h * kFnvPrime + g; }
+template <int D>
+__device__ __forceinline__ uint64_t iter_digest(uint32_t nearest, const double q_new[D], int dim, bool ok) {
+    uint64_t g = fnv_mix(kFnvBasis, (uint64_t)nearest);
+#pragma unroll
+    for (int k = 0; k < D; ++k) if (k < dim) g = fnv_mix(g, (uint64_t)__double_as_longlong(q_new[k]));
+    return fnv_mix(g, ok ? 1ull : 0ull);
+}
+
 }  // namespace oxhip

@@ -445,10 +445,7 @@ __global__ __launch_bounds__(kPipeThreads) void rrt_resident_kernel(DevParams p)
                     }
                 }
                 // bookkeeping (wave-uniform, on the scalar unit where the compiler can)
-                uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
-#pragma unroll
-                for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(q_new[k])));
-                st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
+                st.checksum = uni64(chk_push(st.checksum, iter_digest<D>(nearest, q_new, DIM, ok)));
                 st.iterations++;
                 draws_done = uni64((uint64_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_r, l0) |
                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_r >> 32), l0) << 32));

@@ -677,14 +677,13 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
                 }
             }
             if (!special) {
+                // every lane group digests its own iteration (in parallel); the chain over the batch is one multiply-add each
+                const uint64_t g_l = iter_digest<D>(nearest_r, qn, DIM, ok_l);
                 uint64_t h = st.checksum;
 #pragma unroll
-                for (int r = 0; r < kBatch32; ++r) {
-                    h = fnv_mix(h, (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)nearest_r, kRowLanes * r));
-#pragma unroll
-                    for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(readlane_f64(qn[k], kRowLanes * r))));
-                    h = fnv_mix(h, (uint64_t)((okmask >> r) & 1u));
-                }
+                for (int r = 0; r < kBatch32; ++r)
+                    h = chk_push(h, ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(g_l >> 32), kRowLanes * r) << 32) |
+                                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)g_l, kRowLanes * r));
                 st.checksum = h;
                 st.iterations += kBatch32;
                 st.accepted += (uint64_t)__popc(okmask);
@@ -739,10 +738,7 @@ __global__ __launch_bounds__(kPipeThreads32) void rrt_resident32_kernel(DevParam
                         ok = motion_lanes<DIM>(p, lane, qnr, q_new, oc, othr, ofilt, ns64);
                     }
                 }
-                uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
-#pragma unroll
-                for (int k = 0; k < D; ++k) h = fnv_mix(h, uni64((uint64_t)__double_as_longlong(q_new[k])));
-                st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
+                st.checksum = uni64(chk_push(st.checksum, iter_digest<D>(nearest, q_new, DIM, ok)));
                 st.iterations++;
                 draws_done = uni64((uint64_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_r, l0) |
                                    ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_r >> 32), l0) << 32));

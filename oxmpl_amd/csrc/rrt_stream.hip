@@ -148,10 +148,7 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
         bool bad = motion_invalid_wg<D>(p, dim, q_near, q_new, tid, kStreamThreads);
         const bool ok = !__syncthreads_or(bad ? 1 : 0);
 
-        uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
-#pragma unroll
-        for (int k = 0; k < D; ++k) if (k < dim) h = fnv_mix(h, (uint64_t)__double_as_longlong(q_new[k]));
-        st.checksum = fnv_mix(h, ok ? 1ull : 0ull);
+        st.checksum = chk_push(st.checksum, iter_digest<D>(nearest, q_new, dim, ok));
         st.iterations++;
 
         bool hit = false;

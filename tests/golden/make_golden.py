@@ -179,6 +179,7 @@ def check_motion(field, bounds, fraction, frm, to):
 
 
 FNV_P = 0x100000001B3
+FNV_BASIS = 0xCBF29CE484222325
 
 
 def rrt_solve(dim, bounds, max_distance, goal_bias, fraction, field, start, goal_c, goal_r,
@@ -213,10 +214,12 @@ def rrt_solve(dim, bounds, max_distance, goal_bias, fraction, field, start, goal
         else:
             q_new = list(q_rand)
         ok = check_motion(field, bounds, fraction, q_near, q_new)
-        chk = ((chk ^ nearest) * FNV_P) & M64
+        # checksum (build-defined): digest of the iteration folded from the FNV basis, then H <- H * P + g (mod 2^64)
+        g = ((FNV_BASIS ^ nearest) * FNV_P) & M64
         for v in q_new:
-            chk = ((chk ^ f64_bits(v)) * FNV_P) & M64
-        chk = ((chk ^ int(ok)) * FNV_P) & M64
+            g = ((g ^ f64_bits(v)) * FNV_P) & M64
+        g = ((g ^ int(ok)) * FNV_P) & M64
+        chk = (chk * FNV_P + g) & M64
         iterations += 1
         hit = False
         if ok:

@@ -17,9 +17,10 @@ pytestmark = pytest.mark.gpu
 from oxmpl_amd import capi, scenarios  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
 
-KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32]   # KERNEL_PRUNED: experiment, not in the product build
+KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES]   # KERNEL_PRUNED: experiment, not in the product build
 KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_PRUNED: "pruned",
-         capi.KERNEL_RESIDENT_F32: "resident_f32"}
+         capi.KERNEL_RESIDENT_F32: "resident_f32", capi.KERNEL_LANES: "lanes"}
+SCREENED = (capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES)   # kernels that count their exact-path events (stamps()[4])
 
 
 def _batch_or_skip(*args, **kw):
@@ -295,7 +296,7 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
             lo = rng.random((nb, dim)) * 6.0 - 1.0
             sc["boxes"] = (lo, lo + rng.random((nb, dim)) * 0.8 + 0.1)
         P = 6
-        if kernel in (capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED, capi.KERNEL_RESIDENT_F32) and dim not in (2, 3):
+        if kernel in (capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED, capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES) and dim not in (2, 3):
             continue  # the resident kernel is instantiated for R^2 / R^3 only
         gpu = _gpu_for(sc, P, 400, False, 7, 100, kernel)
         gpu.solve(500)
@@ -482,7 +483,7 @@ def test_screen_margin_sweep(kernel):
             assert o.set_tree(tree, parents) == 0
             gpu.set_tree(p, tree, parents)
             planners.append(o)
-        if kernel == capi.KERNEL_RESIDENT_F32:
+        if kernel in SCREENED:
             gpu.enable_stamps(True)
         gpu.solve(8, freeze=True)
         c = gpu.counts()
@@ -490,16 +491,16 @@ def test_screen_margin_sweep(kernel):
             o.solve(8, freeze=True)
             assert int(c["checksum"][p]) == o.checksum, (eps, pairs[p])
             assert int(c["iterations"][p]) == o.iterations == 8
-        if kernel == capi.KERNEL_RESIDENT_F32:
+        if kernel in SCREENED:
             amb_by_eps[eps] = int(gpu.stamps()[4])
         # the planted trees keep growing identically (inserts on, same fixed query: duplicates and near-ties galore)
-        gpu.enable_stamps(False) if kernel == capi.KERNEL_RESIDENT_F32 else None
+        gpu.enable_stamps(False) if kernel in SCREENED else None
         gpu.solve(40)
         for p, o in enumerate(planners):
             o.solve(40)
             _assert_same_problem(gpu, p, o)
         gpu.close()
-    if kernel == capi.KERNEL_RESIDENT_F32:
+    if kernel in SCREENED:
         for eps, n_amb in amb_by_eps.items():
             if eps <= 2.0 ** -22:
                 assert n_amb > 0, ("the screen decided a pair it cannot separate", eps, amb_by_eps)

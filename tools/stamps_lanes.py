@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic counters of the lane-per-query kernel (workgroup 0): rounds, lanes per round, conflict cuts, exact-path events.
+usage: stamps_lanes.py [P] [iters]   (grow phase, then `iters` frozen iterations)"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oxmpl_amd import capi, scenarios  # noqa: E402
+
+sc = scenarios.config2()
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+gpu = scenarios.make_batch(sc, P, 10000, False, 42, 0, 0, capi.KERNEL_LANES)
+gpu.enable_stamps(True)
+gpu.solve(10 ** 7)
+s = gpu.stamps()
+print("grow: kernel %.3f ms; problem 0: %d iterations in %d rounds (%.1f lanes offered, %.1f committed per round), %d conflict cuts, %d exact-path"
+      % (gpu.last_timing()["kernel_ms"], int(s[7]), int(s[5]), int(s[6]) / max(1, int(s[5])), int(s[7]) / max(1, int(s[5])), int(s[12]), int(s[4])))
+gpu.solve(iters, freeze=True)
+s2 = gpu.stamps()
+it = int(s2[7]) - int(s[7])
+print("steady@10k: kernel %.3f ms (diagnostic build); problem 0: %d iterations in %d rounds (%.1f per round), %d exact-path"
+      % (gpu.last_timing()["kernel_ms"], it, int(s2[5]), it / max(1, int(s2[5])), int(s2[4])))
+print("resolver: wait %.0f  work %.0f cycles per iteration (%.0f per round)" % (int(s2[1]) / it, int(s2[2]) / it, int(s2[2]) / max(1, int(s2[5]))))
+print("scanner waves: wait   ", " ".join("%6.0f" % (int(v) / it) for v in s2[16:24]))
+print("               work   ", " ".join("%6.0f" % (int(v) / it) for v in s2[24:32]))
