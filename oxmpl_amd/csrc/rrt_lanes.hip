@@ -1,23 +1,37 @@
-// rrt_lanes.hip -- the register-resident RRT grow kernel with a LANE-PER-QUERY resolver.
+// rrt_lanes.hip -- the register-resident RRT grow kernel: binary32 dot-product SCREEN + lane-per-query resolver.
 //
-// Same idea as rrt_resident32.hip -- the tree of one planning problem lives in the vector registers of eight scanner
-// waves as binary32 roundings, the O(n) scan of rrt.rs:187-196 is a packed-binary32 SCREEN, and everything that enters
-// a result is computed in binary64 from the binary64 nodes -- but the wave that turns screen results into iterations is
-// organised the other way round.  rrt_resident32's resolver gives every query a group of 8 lanes and handles 8 queries per
-// pass: steer (a binary64 sqrt and a division), the midpoint filter, the checksum chain are then paid per 8 queries, and that
-// wave, not the scan, bounds the kernel (about 1,100 cycles per iteration).  Here lane j of the resolver IS
-// query jr + j: up to 64 iterations are resolved side by side, so one sqrt / division / filter pass serves 64 queries.
+// The tree of one planning problem lives in the vector registers of eight scanner waves, as in rrt_resident32.hip, but
+// both ends of the pipeline are rebuilt around what the chip actually issues (tools/valu_mix_bench.hip: every VALU
+// instruction of the old screen -- packed f32, and_or, med3, min -- costs one ~1.9 ns issue slot per wave64):
+//
+// * Scanners: 2.5 instructions per (64-node register row, query) instead of 6.  A node is held as a = fl32(x - c0) (c0 =
+//   the centre of the bounds) plus cc = fl32(|a|^2), a query as Q = -2 fl32(q - c0), and the screen value is
+//       s' = cc + a . Q  =  |a - b|^2 - |b|^2          (b = fl32(q - c0): D packed fused multiply-adds for two queries),
+//   which orders the nodes like their squared distance.  The only bookkeeping per (row, query) is one v_min_f32: a lane
+//   keeps its smallest s', a wave publishes (smallest s', the lane that holds it, the smallest s' of its OTHER lanes).
+// * Resolver: lane j IS query jr + j (up to 64 iterations resolved side by side; one sqrt / division / filter pass serves
+//   64 queries).  A lane takes the winning scanner lane's own <= 24 nodes -- four consecutive indices per register-row
+//   block, so 32-byte loads from the binary64 tree -- and the nodes committed after the scans' snapshots (LDS ring), computes
+//   their distances in binary64 exactly as the reference does, and keeps the nearest (lowest index on ties, near-ties
+//   flagged).  It ACCEPTS that node only if every node it did not look at is provably farther:
+//       g  <  K2 + |b|^2 - 2 E,      K2 = smallest s' among all other scanner lanes,   E = u H^2 D (3D + 9)
+//   (error model below).  Otherwise -- ~1e-3 of queries -- the query is resolved alone by the reference's literal loop over
+//   the binary64 tree.  Everything that enters a result (distance, steer, motion check, tree, checksum) is binary64.
 //
 // Sequential semantics (iteration k sees exactly the tree left by iterations < k, rrt.rs:170-225) are kept by committing,
 // per round, the longest prefix of the 64 lanes whose results cannot have been changed by the nodes the lanes before them
 // insert (a new node changes a later query's result only if it is at least as close as that query's nearest node: one d2
 // per pair, lane-parallel), and re-resolving the rest in the next round against the grown tree.  With inserts suppressed
 // (the steady measurement) every round commits all its lanes; while a tree is small a round commits ~sqrt(2n) lanes.
-// A lane whose winner the screen cannot prove, or whose binary64 candidates are within a rounding of each other, ends the
-// prefix and is resolved alone by the reference's literal loop over the binary64 tree (post-sqrt compare, lowest index).
 //
-// Waves: 8 scanners (64 x 20 register rows = 10,240 nodes), 1 resolver, 1 sampler (draws the queries ahead: they depend on
-// the RNG stream only).  LDS rings: 128 queries in flight, the last 256 committed nodes.  No workgroup barrier in steady state.
+// Error model (u = 2^-24; H = largest |coordinate - c0| among the bounds, the goal centre and the tree; R^2 <= D H^2):
+//   a = fl32(x - c0), b = fl32(q - c0):  |(a - b) - (x - q)|_k <= 2 u' H,  so  | |a - b| - d | <= 2 u' sqrt(D) H  and, with
+//   |a - b| <= 2 sqrt(D) H,   d^2 >= |a - b|^2 - 8 u' D H^2;
+//   cc = fl32(|a|^2) and the D fused multiply-adds round values of magnitude <= 3 R^2:  |s' + |b|^2 - |a - b|^2| <= (3D + 1) u R^2.
+//   Hence every node with screen value s' has  d^2 >= s' + |b|^2 - E,  E = u H^2 D (3D + 9); the kernel uses 2E.
+//
+// Waves: 8 scanners (six hold S register rows, the two that share a SIMD with the resolver C), 1 resolver, 1 sampler (draws
+// the queries ahead: they depend on the RNG stream only).  LDS rings: 128 queries in flight, the last 256 committed nodes.
 //
 // Replaces the loop body of RRT::solve, oxmpl/src/geometric/planners/rrt.rs:170-225.
 #include "oxhip_internal.hpp"
@@ -32,18 +46,54 @@ constexpr int kLanesThreads = kScanThreads + 128;   // + the resolver wave + the
 constexpr int kQRing = 128;                         // queries in flight (power of two)
 constexpr int kNRing = 256;                         // committed nodes kept in LDS (power of two, >= kQRing + 64)
 constexpr int kPassQ = 8;                           // queries one scanner pass covers
-constexpr uint32_t kDepthGrow = 64;                 // queries sampled ahead of the resolver while inserts are on
-constexpr uint32_t kLKeyInf = 0x7F80001Fu;          // +inf with slot 31: "no node"
-constexpr uint32_t kLSlotMask = 31u;
+constexpr uint32_t kDepthGrow = 96;                 // queries sampled ahead of the resolver while inserts are on
 #ifndef OXHIP_LANES_PRIO
 #define OXHIP_LANES_PRIO 16
 #endif
 
 struct alignas(16) LanePub {   // one wave's screen result for one query (one 16-byte LDS record)
-    uint32_t k1;   // smallest key of the wave
-    uint32_t k2;   // second smallest key of the wave (with multiplicity)
-    uint32_t i1;   // node index of k1
+    uint32_t k1;   // bits of the smallest screen value s' of the wave
+    uint32_t k2;   // bits of the smallest s' among the wave's other lanes
+    uint32_t th;   // scanner thread (wave * 64 + lane) that holds k1
     uint32_t nc;   // tree size this scan covered (the wave's snapshot of `committed`)
+};
+
+// Node -> (scanner thread, register row) in blocks of four rows: a thread's four rows of a block are four CONSECUTIVE node
+// indices, so the resolver fetches a scanner lane's candidates with 32-byte loads.  Blocks 0 .. C/4-1 span all 512 scanner
+// threads (2048 nodes each); blocks C/4 .. S/4-1 only the 384 threads of waves 1,2,3,5,6,7 (1536 nodes each): waves 0 and
+// 4 share their SIMD with the resolver and hold fewer rows.
+template <int S, int C>
+struct Layout4 {
+    static_assert(S % 4 == 0 && C % 4 == 0 && C <= S, "rows come in blocks of four");
+    static constexpr uint32_t kCommonNodes = (uint32_t)C * 512u;
+    static constexpr uint32_t kCapacity = kCommonNodes + (uint32_t)(S - C) * 384u;
+    __device__ static __forceinline__ bool heavy(uint32_t wave) { return (wave & 3u) != 0; }
+    __device__ static __forceinline__ uint32_t rows(uint32_t wave) { return heavy(wave) ? (uint32_t)S : (uint32_t)C; }
+    // first node of block `blk` of scanner thread `th` (kNoNode when that wave does not hold the block)
+    __device__ static __forceinline__ uint32_t block_base(uint32_t th, uint32_t blk) {
+        if (blk < (uint32_t)(C / 4)) return blk * 2048u + th * 4u;
+        const uint32_t wave = th >> 6;
+        if (!heavy(wave)) return kNoNode;
+        const uint32_t hw = wave - 1u - (wave > 4u ? 1u : 0u);   // waves 1,2,3,5,6,7 -> 0..5
+        return kCommonNodes + (blk - (uint32_t)(C / 4)) * 1536u + (hw * 64u + (th & 63u)) * 4u;
+    }
+    __device__ static __forceinline__ void locate(uint32_t i, uint32_t& thread, uint32_t& row) {
+        if (i < kCommonNodes) { thread = (i & 2047u) >> 2; row = (i >> 11) * 4u + (i & 3u); return; }
+        const uint32_t r = i - kCommonNodes, blk = r / 1536u, c = r % 1536u, ht = c >> 2, hw = ht >> 6;
+        row = (uint32_t)C + blk * 4u + (c & 3u);
+        thread = (hw + 1u + (hw >= 3u ? 1u : 0u)) * 64u + (ht & 63u);
+    }
+    // rows of `wave` that may hold a node when the tree has n nodes (a multiple of four: whole blocks)
+    __device__ static __forceinline__ uint32_t rows_in_use(uint32_t wave, uint32_t n) {
+        if (n <= kCommonNodes) {
+            const uint32_t full = n >> 11, rem = n & 2047u;
+            return 4u * full + (rem > wave * 256u ? 4u : 0u);
+        }
+        if (!heavy(wave)) return (uint32_t)C;
+        const uint32_t r = n - kCommonNodes, full = r / 1536u, rem = r % 1536u;
+        const uint32_t hw = wave - 1u - (wave > 4u ? 1u : 0u);
+        return (uint32_t)C + 4u * full + (rem > hw * 256u ? 4u : 0u);
+    }
 };
 
 template <int DIM>
@@ -51,27 +101,29 @@ struct LanesShared {
     uint32_t rng_buf[16][64];
     double q[DIM][kQRing];               // the queries, coordinate-major: resolver lane j reads q[k][slot_j] conflict-free
     uint64_t pos_after[kQRing];          // stream position after each query's draws
-    float qf[kQRing][4];                 // fl32(q): what the scanners screen with (one 16-byte uniform read per query)
+    float qf[kQRing][4];                 // Q = -2 fl32(q - c0): what the scanners screen with (one 16-byte uniform read per query)
     LanePub pub[kScanWaves][kQRing];     // wave-major: resolver lane j reads pub[w][slot_j] conflict-free
     double newn[DIM][kNRing];            // the last kNRing committed nodes, node i at i & (kNRing - 1); +inf for skipped duplicates
     double obs[DIM + 2][64];             // first 64 spheres: centre, validity threshold, filter threshold
     uint32_t wave_done[kScanWaves];      // queries each scanner wave has published (monotonic)
     uint32_t sampled, resolved, committed, stop_flag;
     uint32_t heartbeat;                  // bumped by the resolver while it works: waiters only give up when it stands still
-    uint32_t mabs_bits;                  // bits of the largest |fl32(coordinate)| the scanners loaded
+    uint32_t mabs_bits;                  // bits of the largest |fl32(coordinate - c0)| the scanners loaded
 };
 
 __device__ __forceinline__ uint32_t lf32_bits(float v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ float lbits_f32(uint32_t v) { return __builtin_bit_cast(float, v); }
 
-// wave-wide unsigned minima of four independent values (see rrt_resident32.hip: one v_min_u32_dpp per value and step)
+// wave-wide float minima of four independent values, one v_min_f32_dpp per value and step (the four chains interleave, so a
+// value's next step is three instructions behind its last write: no hazard padding beyond the leading s_nop).  Lanes a
+// step gives no source keep their value.  The values are finite or +inf (never NaN: see the scanner).
 #define OXHIP_LMIN4_STEP(ctrl)                  \
-    "v_min_u32_dpp %0, %0, %0 " ctrl "\n"       \
-    "v_min_u32_dpp %1, %1, %1 " ctrl "\n"       \
-    "v_min_u32_dpp %2, %2, %2 " ctrl "\n"       \
-    "v_min_u32_dpp %3, %3, %3 " ctrl "\n"
-__device__ __forceinline__ void lanes_min4_u32(uint32_t (&v)[4]) {
-    uint32_t a = v[0], b = v[1], c = v[2], d = v[3];
+    "v_min_f32_dpp %0, %0, %0 " ctrl "\n"       \
+    "v_min_f32_dpp %1, %1, %1 " ctrl "\n"       \
+    "v_min_f32_dpp %2, %2, %2 " ctrl "\n"       \
+    "v_min_f32_dpp %3, %3, %3 " ctrl "\n"
+__device__ __forceinline__ void lanes_min4_f32(float (&v)[4]) {
+    float a = v[0], b = v[1], c = v[2], d = v[3];
     asm("s_nop 1\n"
         OXHIP_LMIN4_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
         OXHIP_LMIN4_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
@@ -80,21 +132,14 @@ __device__ __forceinline__ void lanes_min4_u32(uint32_t (&v)[4]) {
         OXHIP_LMIN4_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
         OXHIP_LMIN4_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    v[0] = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
-    v[1] = (uint32_t)__builtin_amdgcn_readlane((int)b, 63);
-    v[2] = (uint32_t)__builtin_amdgcn_readlane((int)c, 63);
-    v[3] = (uint32_t)__builtin_amdgcn_readlane((int)d, 63);
+    v[0] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(a), 63));
+    v[1] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(b), 63));
+    v[2] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(c), 63));
+    v[3] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(d), 63));
 }
 #undef OXHIP_LMIN4_STEP
-
-struct LScreen {
-    uint32_t b1;   // smallest key
-    uint32_t h2;   // second smallest key (with multiplicity)
-};
-__device__ __forceinline__ void lscreen_push(LScreen& v, float s, uint32_t slot) {
-    const uint32_t key = (lf32_bits(s) & ~kLSlotMask) | slot;
-    v.h2 = umed3(key, v.b1, v.h2);
-    v.b1 = key < v.b1 ? key : v.b1;
+__device__ __forceinline__ void vmin_f32(float& acc, float x) {   // plain v_min_f32 in place: no canonicalising v_max in front,
+    asm("v_min_f32 %0, %0, %1" : "+v"(acc) : "v"(x));             // and no renamed register to copy back where branches join
 }
 
 // wave-wide sum of a 64-bit value (mod 2^64); every lane of the last row holds it, lane 63 is read
@@ -122,7 +167,7 @@ __device__ __forceinline__ uint64_t first_n_mask(uint32_t n) { return n >= 64u ?
 // Lane-parallel sampling of m <= 64 consecutive queries into the coordinate-major ring: sample_batch of
 // rrt_resident_common.hpp (rrt.rs:177-184 + rvss.rs:233-249) with this kernel's ring layout and the fl32 copies.
 template <int DIM>
-__device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m,
+__device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p, const double* goal_c, const double* c0, uint32_t m,
                                              uint32_t lane, LanesShared<DIM>& sh, uint32_t js) {
     const uint64_t win_lo = rng.base_blk * 8;
     const uint64_t pos0 = rng.pos;
@@ -164,7 +209,7 @@ __device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p,
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
             sh.q[k][slot] = q[k];
-            sh.qf[slot][k] = (float)q[k];
+            sh.qf[slot][k] = -2.0f * (float)(q[k] - c0[k]);
         }
         sh.pos_after[slot] = pos0 + off + cnt;
     }
@@ -173,19 +218,39 @@ __device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p,
 }
 
 struct LMargins {
-    double a2;        // 2A
-    double r_lo;      // 1 - 2R
-    double r_hi;      // 1 + 2R
-    bool usable;      // M small enough for binary32 squares
+    double e2;        // 2E: twice the bound on |s' + |b|^2 - d^2|
+    bool usable;      // H small enough for binary32 products
 };
+
+template <int DIM, int S, int ROW>
+__device__ __forceinline__ void absorb_one(lf32x2 (&tr)[DIM][S / 2], lf32x2 (&tcc)[S / 2], bool mine, const float (&f)[DIM], float fcc) {
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) tr[k][ROW / 2][ROW % 2] = f[k];
+        tcc[ROW / 2][ROW % 2] = fcc;
+    }
+}
+// binary descent on the wave-uniform row number: log2(S) scalar branches, then the one row's predicated writes
+template <int DIM, int S, int LO, int HI>
+__device__ __forceinline__ void absorb_range(lf32x2 (&tr)[DIM][S / 2], lf32x2 (&tcc)[S / 2], uint32_t row, bool mine, const float (&f)[DIM], float fcc) {
+    if constexpr (HI - LO == 1) {
+        absorb_one<DIM, S, LO>(tr, tcc, mine, f, fcc);
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (row < (uint32_t)MID) absorb_range<DIM, S, LO, MID>(tr, tcc, row, mine, f, fcc);
+        else absorb_range<DIM, S, MID, HI>(tr, tcc, row, mine, f, fcc);
+    }
+}
+template <int DIM, int S>
+__device__ __forceinline__ void absorb_row(lf32x2 (&tr)[DIM][S / 2], lf32x2 (&tcc)[S / 2], uint32_t row, bool mine, const float (&f)[DIM], float fcc) {
+    absorb_range<DIM, S, 0, S>(tr, tcc, row, mine, f, fcc);
+}
 
 template <int DIM, int S, int C, bool STAMP>
 __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     constexpr int D = DIM;
-    static_assert(S <= 32, "the slot number lives in 5 key bits");
     static_assert(DIM <= 4, "qf holds four floats per query");
-    // Scanner waves 0 and 4 share their SIMD with the resolver: they hold C rows, the other six S (rrt_resident_common.hpp)
-    using Lay = Layout<S, C, false>;
+    using Lay = Layout4<S, C>;
 
     const uint32_t prob = blockIdx.x;
     const uint32_t tid = threadIdx.x;
@@ -202,6 +267,9 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     uint8_t* skip = p.skip + (size_t)prob * cap;
     const uint32_t budget = (uint32_t)p.budget;  // the host keeps a launch's budget below 2^31
     const uint32_t depth = p.freeze ? (uint32_t)kQRing : kDepthGrow;
+    double c0[D];   // the centre of the bounds: the screen works on coordinates relative to it
+#pragma unroll
+    for (int k = 0; k < D; ++k) c0[k] = 0.5 * p.lo[k] + 0.5 * p.hi[k];
 
     if (tid < (uint32_t)kScanWaves) sh.wave_done[tid] = 0;
     if (tid == 0) {
@@ -216,20 +284,31 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 
     if (wave < kScanWaves) {
         // ================================================================= scanner waves
+        // rows in pairs: a packed instruction's operand is a 64-bit register pair anyway, and op_sel picks the half that is
+        // broadcast to both halves of the operation (S x (D + 1) VGPRs of tree instead of twice that)
         uint32_t n_local = st0.n_nodes;
-        float tr[DIM][S];
+        lf32x2 tr[DIM][S / 2], tcc[S / 2];
         uint32_t mab = 0;
+        const uint32_t my_rows = Lay::rows(wave);
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const uint32_t i = ((uint32_t)s < Lay::kCommon || Lay::heavy(wave)) ? Lay::node_index(wave, lane, (uint32_t)s) : kNoNode;
-            const bool in_tree = i < n_local;
-            const bool live = in_tree && skip[i] == 0;  // duplicates of a lower-index node never win: hold +inf
+        for (int blk = 0; blk < S / 4; ++blk) {
+            const uint32_t ib = Lay::block_base(tid, (uint32_t)blk);
 #pragma unroll
-            for (int k = 0; k < DIM; ++k) {
-                const float f = in_tree ? (float)tree[(size_t)k * cap + i] : 0.0f;
-                const uint32_t ab = lf32_bits(f) & 0x7FFFFFFFu;
-                mab = ab > mab ? ab : mab;
-                tr[k][s] = live ? f : __builtin_inff();
+            for (int t = 0; t < 4; ++t) {
+                const int s = 4 * blk + t;
+                const uint32_t i = ib == kNoNode ? kNoNode : ib + (uint32_t)t;
+                const bool in_tree = i < n_local;
+                const bool live = in_tree && skip[in_tree ? i : 0u] == 0;  // duplicates of a lower-index node never win: hold +inf
+                double sq = 0.0;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) {
+                    const float f = in_tree ? (float)(tree[(size_t)k * cap + (in_tree ? i : 0u)] - c0[k]) : 0.0f;
+                    const uint32_t ab = lf32_bits(f) & 0x7FFFFFFFu;
+                    mab = ab > mab ? ab : mab;
+                    tr[k][s / 2][s % 2] = live ? f : 0.0f;
+                    sq += (double)f * (double)f;
+                }
+                tcc[s / 2][s % 2] = live ? (float)sq : __builtin_inff();
             }
         }
         __hip_atomic_fetch_max(&sh.mabs_bits, mab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -266,20 +345,22 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             for (uint32_t i = n_local; i < nc; ++i) {
                 uint32_t owner_thread, sl;
                 Lay::locate(i, owner_thread, sl);
-                if ((owner_thread >> 6) != wave) continue;   // another wave's node: skip the slot ladder below
+                if ((owner_thread >> 6) != wave) continue;   // another wave's node: skip the row ladder below
                 const bool mine = tid == owner_thread;
+                float f[D];
+                double sq = 0.0;
+                const bool dupn = !(sh.newn[0][i & (kNRing - 1)] < __builtin_inf());   // the ring holds +inf for a skipped duplicate
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (sl == (uint32_t)s) {
-                        if (mine) {
-#pragma unroll
-                            for (int k = 0; k < D; ++k) tr[k][s] = (float)sh.newn[k][i & (kNRing - 1)];   // +inf stays +inf
-                        }
-                    }
+                for (int k = 0; k < D; ++k) {
+                    f[k] = dupn ? 0.0f : (float)(sh.newn[k][i & (kNRing - 1)] - c0[k]);
+                    sq += (double)f[k] * (double)f[k];
                 }
+                const float fcc = dupn ? __builtin_inff() : (float)sq;
+                // (register arrays cannot be indexed dynamically: the wave-uniform row number selects one of S compile-time copies)
+                absorb_row<DIM, S>(tr, tcc, uni(sl), mine, f, fcc);
             }
             n_local = nc;
-            // the pass's queries, two per packed register
+            // the pass's queries Q = -2 fl32(q - c0), two per packed register
             lf32x2 q[kPassQ / 2][D];
 #pragma unroll
             for (int b = 0; b < kPassQ; ++b) {
@@ -287,54 +368,59 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = lbits_f32(uni(lf32_bits(sh.qf[slot][k])));   // wave-uniform: scalar registers
             }
-            const uint32_t nslots = Lay::slots_in_use(wave, nc);
-            LScreen sc[kPassQ];
+            uint32_t nrows = Lay::rows_in_use(wave, nc);
+            if (nrows > my_rows) nrows = my_rows;
+            float b1[kPassQ];
 #pragma unroll
-            for (int b = 0; b < kPassQ; ++b) sc[b] = LScreen{kLKeyInf, kLKeyInf};
-            // screen (rrt.rs:187-196 in binary32): groups of kGroup slots under one uniform branch
+            for (int b = 0; b < kPassQ; ++b) b1[b] = __builtin_inff();
+            // screen (rrt.rs:187-196 as s' = cc + a . Q in binary32): blocks of four rows under one uniform branch
 #pragma unroll
-            for (int g0 = 0; g0 < S; g0 += group_len<S, C>(g0)) {
-                if ((uint32_t)g0 < nslots) {
+            for (int g0 = 0; g0 < S; g0 += 4) {
+                if ((uint32_t)g0 < nrows) {
 #pragma unroll
-                    for (int s = g0; s < g0 + group_len<S, C>(g0); ++s) {
+                    for (int s = g0; s < g0 + 4; ++s) {
+                        // the four query pairs' chains side by side: consecutive instructions are independent
+                        lf32x2 acc[kPassQ / 2];
+#pragma unroll
+                        for (int bp = 0; bp < kPassQ / 2; ++bp)
+                            acc[bp] = (s & 1) ? __builtin_shufflevector(tcc[s / 2], tcc[s / 2], 1, 1) : __builtin_shufflevector(tcc[s / 2], tcc[s / 2], 0, 0);
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const lf32x2 a = (s & 1) ? __builtin_shufflevector(tr[k][s / 2], tr[k][s / 2], 1, 1) : __builtin_shufflevector(tr[k][s / 2], tr[k][s / 2], 0, 0);
+#pragma unroll
+                            for (int bp = 0; bp < kPassQ / 2; ++bp) acc[bp] = __builtin_elementwise_fma(a, q[bp][k], acc[bp]);
+                        }
 #pragma unroll
                         for (int bp = 0; bp < kPassQ / 2; ++bp) {
-                            lf32x2 e = (lf32x2){tr[0][s], tr[0][s]} - q[bp][0];
-                            lf32x2 acc = e * e;
-#pragma unroll
-                            for (int k = 1; k < D; ++k) {
-                                e = (lf32x2){tr[k][s], tr[k][s]} - q[bp][k];
-                                acc = __builtin_elementwise_fma(e, e, acc);
-                            }
-                            lscreen_push(sc[2 * bp], acc[0], (uint32_t)s);
-                            lscreen_push(sc[2 * bp + 1], acc[1], (uint32_t)s);
+                            vmin_f32(b1[2 * bp], acc[bp][0]);
+                            vmin_f32(b1[2 * bp + 1], acc[bp][1]);
                         }
                     }
                 }
             }
-            // reduce: the wave's smallest key, its lane, and the smallest of everything else
-            uint32_t k1w[kPassQ], k2w[kPassQ];
+            // reduce: the wave's smallest s', the lane that holds it, and the smallest among the other lanes
+            float k1w[kPassQ], k2w[kPassQ];
             int wl[kPassQ];
 #pragma unroll
             for (int b0 = 0; b0 < kPassQ; b0 += 4) {
-                uint32_t t4[4];
+                float t4[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) t4[t] = sc[b0 + t].b1;
-                lanes_min4_u32(t4);
+                for (int t = 0; t < 4; ++t) t4[t] = b1[b0 + t];
+                lanes_min4_f32(t4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) k1w[b0 + t] = t4[t];
             }
 #pragma unroll
             for (int b = 0; b < kPassQ; ++b) {
-                const uint64_t eqm = __ballot(sc[b].b1 == k1w[b]);
-                wl[b] = __ffsll((unsigned long long)eqm) - 1;   // eqm != 0: the minimum is attained
+                const uint64_t eqm = __ballot(lf32_bits(b1[b]) == lf32_bits(k1w[b]));
+                wl[b] = eqm ? __ffsll((unsigned long long)eqm) - 1 : 0;
             }
 #pragma unroll
             for (int b0 = 0; b0 < kPassQ; b0 += 4) {
-                uint32_t t4[4];
+                float t4[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) t4[t] = (int)lane == wl[b0 + t] ? sc[b0 + t].h2 : sc[b0 + t].b1;
-                lanes_min4_u32(t4);
+                for (int t = 0; t < 4; ++t) t4[t] = (int)lane == wl[b0 + t] ? __builtin_inff() : b1[b0 + t];
+                lanes_min4_f32(t4);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) k2w[b0 + t] = t4[t];
             }
@@ -344,9 +430,9 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                     const uint32_t slot = (j + (uint32_t)b) & (kQRing - 1);
                     if (lane == 0) {
                         LanePub out;
-                        out.k1 = k1w[b];
-                        out.k2 = k2w[b];
-                        out.i1 = Lay::node_index(wave, (uint32_t)wl[b], k1w[b] & kLSlotMask);
+                        out.k1 = lf32_bits(k1w[b]);
+                        out.k2 = lf32_bits(k2w[b]);
+                        out.th = wave * 64u + (uint32_t)wl[b];
                         out.nc = nc;
                         sh.pub[wave][slot] = out;
                     }
@@ -383,7 +469,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                     spins = 0;
                 }
                 jr_seen = uni(lds_peek(&sh.resolved));
-                if (js - jr_seen <= depth / 2) { go = true; break; }   // half the window is free: refill it
+                if (js - jr_seen + 16u <= depth) { go = true; break; }   // two scanner passes' worth of the window is free: refill it
                 __builtin_amdgcn_s_sleep(2);
             }
             if (!go) break;  // stop requested (or a protocol bug: the resolver's own guard reports it)
@@ -400,7 +486,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                 for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
             }
-            if (!sample_lanes<DIM>(rng, p, goal_c, m, lane, sh, js)) {
+            if (!sample_lanes<DIM>(rng, p, goal_c, c0, m, lane, sh, js)) {
                 for (uint32_t b = 0; b < m; ++b) {  // (never expected) a redraw ran past the window: one by one
                     double qn[D];
                     sample_state<D, false>(rng, p, DIM, goal_c, qn);
@@ -409,7 +495,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                         for (int k = 0; k < D; ++k) {
                             sh.q[k][slot] = qn[k];
-                            sh.qf[slot][k] = (float)qn[k];
+                            sh.qf[slot][k] = -2.0f * (float)(qn[k] - c0[k]);
                         }
                         sh.pos_after[slot] = rng.pos;
                     }
@@ -459,36 +545,31 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     uint32_t n = st.n_nodes;
     uint32_t jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
-    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
+    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
+    const uint64_t t_begin = t_mark, rt_begin = STAMP ? (uint64_t)__builtin_amdgcn_s_memrealtime() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
     LMargins mg;
     {
-        // M: the tree as loaded (binary32 roundings, hence the 1 + 2^-23), the bounds and the goal centre
-        double m = (double)lbits_f32(lds_peek(&sh.mabs_bits)) * (1.0 + 0x1p-23);
+        // H: the tree as loaded (binary32 roundings, hence the 1 + 2^-23), the bounds and the goal centre, relative to c0
+        double h = (double)lbits_f32(lds_peek(&sh.mabs_bits)) * (1.0 + 0x1p-23);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            m = fmax(m, fmax(fabs(p.lo[k]), fabs(p.hi[k])));
-            m = fmax(m, fabs(goal_c[k]));
+            h = fmax(h, fmax(fabs(p.lo[k] - c0[k]), fabs(p.hi[k] - c0[k])));
+            h = fmax(h, fabs(goal_c[k] - c0[k]));
         }
-        m = unid(m) * 1.001;   // interpolation rounding over any chain of inserts
+        h = unid(h) * 1.001;   // interpolation rounding over any chain of inserts
         const double u = 0x1p-24;
-        mg.usable = m < 1e15;  // also false for NaN / inf
-        mg.a2 = 2.0 * (sqrt((double)D) * 4.1 * u * m + 1e-18);
-        const double r2 = 2.0 * (0x1p-19 + (double)(D + 2) * u) + 0x1p-21;   // + the binary32 square root of the clear test
-        mg.r_lo = 1.0 - r2;
-        mg.r_hi = 1.0 + r2;
+        mg.usable = h < 1e15 && fabs(c0[0]) < 1e300;  // also false for NaN / inf
+        mg.e2 = 2.0 * (u * h * h * (double)(D * (3 * D + 9)) * 1.0001 + 1e-290);
     }
 
-    // coordinates of node i as the resolver may read them: the LDS ring for the young ones (their global stores may still be
-    // in flight; duplicates hold +inf there, but a duplicate is never anybody's nearest node), the persistent binary64 copy
-    // in global memory for nodes this wave wrote at least 64 commits ago or that predate the launch
-    auto node_coord = [&](int k, uint32_t i, uint32_t n_now) -> double {
-        const bool young = i >= st0.n_nodes && i + (uint32_t)(kNRing - 64) >= n_now;
-        const double g = __hip_atomic_load(&tree[(size_t)k * cap + (young ? 0u : i)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double l = sh.newn[k][i & (kNRing - 1)];
-        return young ? l : g;
-    };
+    typedef double ldouble4 __attribute__((ext_vector_type(4)));
+    // the last whole-tree answer: valid while the tree has not grown (see the exact path)
+    uint32_t memo_n = 0xFFFFFFFFu, memo_idx = kNoNode;
+    double memo_g = 0.0, memo_q[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) memo_q[k] = 0.0;
 
     while (true) {
         if (jr >= budget) { stop = 1; break; }
@@ -529,44 +610,52 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
         for (int k = 0; k < D; ++k) q[k] = sh.q[k][slot];
         const uint64_t pos_after_l = sh.pos_after[slot];
-        // the eight waves' screens: smallest key, the wave that holds it, the smallest of everything else, oldest snapshot
-        uint32_t K1 = kLKeyInf, K2 = kLKeyInf, cand = 0, bmin = 0xFFFFFFFFu;
+        // this wave's own earlier stores to the tree have reached the cache the loads below read (same CU; a wait, no cache op)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // the eight waves' screens: the scanner lane that holds the smallest s', the smallest s' of every other lane, oldest snapshot
+        float K1 = __builtin_inff(), K2 = __builtin_inff();
+        uint32_t wth = 0, bmin = 0xFFFFFFFFu;
         {
             LanePub rec[kScanWaves];
 #pragma unroll
             for (int w = 0; w < kScanWaves; ++w) rec[w] = sh.pub[w][slot];
 #pragma unroll
             for (int w = 0; w < kScanWaves; ++w) {
-                K1 = rec[w].k1 < K1 ? rec[w].k1 : K1;
+                K1 = fminf(K1, lbits_f32(rec[w].k1));   // (never NaN: see the scanner)
                 bmin = rec[w].nc < bmin ? rec[w].nc : bmin;
             }
             bool taken = false;
 #pragma unroll
             for (int w = 0; w < kScanWaves; ++w) {
-                const bool win = !taken && rec[w].k1 == K1;   // the first wave attaining the minimum
-                const uint32_t other = win ? rec[w].k2 : rec[w].k1;
-                K2 = other < K2 ? other : K2;
-                cand = win ? rec[w].i1 : cand;
+                const bool win = !taken && lbits_f32(rec[w].k1) == K1;   // the first wave attaining the minimum
+                K2 = fminf(K2, lbits_f32(win ? rec[w].k2 : rec[w].k1));
+                wth = win ? rec[w].th : wth;
                 taken = taken || win;
             }
         }
         if (__ballot(act && (n - bmin > (uint32_t)(kNRing - 64) || bmin > n)) != 0) { stop = 4; break; }  // ring would have wrapped (bug guard)
-        bool clear;
-        {
-            const float v1 = lbits_f32(K1 & ~kLSlotMask), v2 = lbits_f32(K2 & ~kLSlotMask);
-            // v_sqrt_f32 (1 ulp; a subnormal argument may come back as 0, which the 1e-18 inside A covers): its 2^-22 is in r_lo / r_hi
-            const double d1 = (double)__builtin_amdgcn_sqrtf(v1), d2 = (double)__builtin_amdgcn_sqrtf(v2);
-            // (+inf second: d2 = +inf and the test holds; +inf or NaN first: it fails)
-            clear = act && mg.usable && K1 != kLKeyInf && (d2 * mg.r_lo - mg.a2 > d1 * mg.r_hi + mg.a2);
-        }
-        // the screen's winner with its binary64 coordinates and d2
-        const uint32_t cand_i = (clear && cand < n) ? cand : 0u;
-        double cc[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) cc[k] = node_coord(k, cand_i, n);
-        const double pb = clear ? dist2<D>(cc, q, DIM) : __builtin_inf();
-        // nodes committed after the oldest snapshot: every lane folds the ones its own query has not seen
+        // the winning scanner lane's own nodes, in binary64 from the tree (four consecutive nodes per block of rows), then
+        // the nodes committed after the oldest snapshot, from the LDS ring: ascending indices, so ties keep the lower index
         Scan pd{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
+#pragma unroll
+        for (int blk = 0; blk < S / 4; ++blk) {
+            const uint32_t ib = Lay::block_base(wth, (uint32_t)blk);
+            const bool have = act && ib < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
+            if (__ballot(have) == 0) continue;       // a small tree fills the first blocks only
+            const uint32_t il = have ? ib : 0u;
+            ldouble4 c4[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) c4[k] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il);
+            const uint32_t sk4 = *reinterpret_cast<const uint32_t*>(skip + il);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                double c[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) c[k] = c4[k][t];
+                const double d = dist2<D>(c, q, DIM);
+                if (have && ib + (uint32_t)t < bmin && ((sk4 >> (8 * t)) & 0xFFu) == 0) scan_push(pd, d, ib + (uint32_t)t);
+            }
+        }
         {
             const uint32_t lo = wave_min_u32(act ? bmin : 0xFFFFFFFFu);
             for (uint32_t i = lo; i < n; ++i) {
@@ -574,21 +663,32 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) c[k] = sh.newn[k][i & (kNRing - 1)];
                 const double d = dist2<D>(c, q, DIM);
-                if (act && i >= bmin) scan_push(pd, d, i);  // ascending i: ties keep the lower index
+                if (act && i >= bmin) scan_push(pd, d, i);  // (+inf for skipped duplicates: never pushed as a minimum)
             }
         }
-        const double g = pd.b1 < pb ? pd.b1 : pb;
+        const double g = pd.b1;
         const uint32_t hb = hi32(g) + 1;
-        const bool nearS = clear && hi32(pb) <= hb;
-        const bool nearP = pd.slot != kNoNode && hi32(pd.b1) <= hb;
-        const uint32_t nearest = nearS ? cand : pd.slot;
-        // ambiguous iff the screen could not name a winner, or a second node is within a rounding of the binary64 minimum
-        const bool amb = act && (!clear || (nearP && pd.slot != nearest) || pd.h2 <= hb || (!nearS && !nearP));
+        const uint32_t nearest = pd.slot;
+        // accept iff every node this lane did not look at -- the other scanner lanes' -- is provably farther:
+        //   d_other^2 >= K2 + |b|^2 - E   >   g
+        bool clear;
+        {
+            double bb = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) { const double bk = (double)(float)(q[k] - c0[k]); bb += bk * bk; }
+            clear = act && mg.usable && nearest != kNoNode && (g < (double)K2 + bb - mg.e2);   // (NaN on either side: false)
+        }
+        // ambiguous iff that proof fails, or a second candidate is within a rounding of the binary64 minimum
+        const bool amb = act && (!clear || pd.h2 <= hb);
         double q_near[D], qn[D], mid[D];
         {
-            const uint32_t ni = (nearest == kNoNode ? 0u : nearest) & (kNRing - 1);
+            const uint32_t ni = nearest == kNoNode ? 0u : nearest;
+            const bool from_ring = ni >= bmin;
 #pragma unroll
-            for (int k = 0; k < D; ++k) q_near[k] = nearS ? cc[k] : sh.newn[k][ni];
+            for (int k = 0; k < D; ++k) {
+                const double gl = tree[(size_t)k * cap + (from_ring ? 0u : ni)];
+                q_near[k] = from_ring ? sh.newn[k][ni & (kNRing - 1)] : gl;
+            }
         }
         steer<DIM>(p, false, g, q_near, q, qn);
         const bool dup = g == 0.0;
@@ -733,35 +833,96 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         if (stop_after >= 0) { stop = stop_after; break; }
         if (cut == m || ambm == 0 || (uint32_t)(__ffsll((unsigned long long)ambm) - 1) != cut) continue;
 
-        // ---- the lane at `cut` is ambiguous: that one query by the reference's own loop -- post-sqrt compare with
-        //      lowest-index ties -- over the persistent binary64 copy of the tree in global memory
+        // ---- the lane at `cut` is ambiguous: that one query over the WHOLE binary64 tree.  First by squared distances, the
+        //      wave striding over the nodes (four in flight per lane): if exactly one node is within a rounding of the
+        //      minimum, it is the reference's nearest node (sqrt is monotone).  Only a genuine near-tie -- two d2 that may
+        //      share a correctly rounded root -- takes the reference's literal loop (post-sqrt compare, lowest index).
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
         {
             if (STAMP) ++n_amb;
+            const uint64_t t_e0 = STAMP ? (uint64_t)clock64() : 0;
             const uint32_t slot1 = jr & (kQRing - 1);
             double q1[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) q1[k] = unid(sh.q[k][slot1]);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            Exact e{__builtin_inf(), kNoNode};
-            for (uint32_t i = lane; i < n; i += 64) {
-                double c[D];
+            // (a fixed query on an unchanged tree has a fixed answer: the goal centre is drawn again and again -- goal_bias --
+            // and when the screen cannot decide it once, it cannot decide it the next time either)
+            bool same_q = memo_n == n;
+#pragma unroll
+            for (int k = 0; k < D; ++k) same_q = same_q && __double_as_longlong(q1[k]) == __double_as_longlong(memo_q[k]);
+            double gmin = memo_g;
+            uint32_t memo_hit_idx = memo_idx;
+            bool tie = false;
+            if (!same_q) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores to the tree have landed (same CU)
+                Scan ps{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
+                // a lane takes four consecutive nodes per 32-byte load and coordinate, four such groups per trip: 16 nodes per
+                // lane in flight (the trees of a whole batch do not fit the L2: a trip is a DRAM / Infinity Cache round trip)
+                for (uint32_t i0 = 4u * lane; i0 < n; i0 += 1024u) {
+                    ldouble4 c4[4][D];
+                    uint32_t sk4[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t ib = i0 + 256u * (uint32_t)t, il = ib < n ? ib : 0u;   // (rows are padded to cap >= n rounded up to 1024)
+#pragma unroll
+                        for (int k = 0; k < D; ++k) c4[t][k] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il);
+                        sk4[t] = *reinterpret_cast<const uint32_t*>(skip + il);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t i = i0 + 256u * (uint32_t)t + (uint32_t)r;
+                            double c[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) c[k] = c4[t][k][r];
+                            const double d = dist2<D>(c, q1, DIM);
+                            if (i < n && ((sk4[t] >> (8 * r)) & 0xFFu) == 0) scan_push(ps, d, i);   // ascending within the lane: ties keep the lower index
+                        }
+                    }
+                }
+                gmin = wave_min_f64(ps.b1);
+                const uint32_t hbw = hi32(gmin) + 1;
+                const uint64_t nearm = __ballot(ps.slot != kNoNode && hi32(ps.b1) <= hbw);
+                tie = __popcll(nearm) != 1 || __ballot(ps.h2 <= hbw) != 0;
+                memo_hit_idx = tie ? kNoNode : (uint32_t)__builtin_amdgcn_readlane((int)ps.slot, __ffsll((unsigned long long)(nearm | (1ull << 63))) - 1);
+                if (!tie) {
+                    memo_n = n; memo_g = gmin; memo_idx = memo_hit_idx;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) memo_q[k] = q1[k];
+                }
+            } else if (STAMP) ++n_memo;
+            uint32_t nearest1;
+            double qn1[D], q_near1[D];
+            bool dup1;
+            if (!tie) {
+                nearest1 = memo_hit_idx;
+#pragma unroll
+                for (int k = 0; k < D; ++k) q_near1[k] = unid(tree[(size_t)k * cap + nearest1]);
+                dup1 = gmin == 0.0;
+                steer<DIM>(p, false, gmin, q_near1, q1, qn1);
+            } else {
+                if (STAMP) ++n_tie;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                Exact e{__builtin_inf(), kNoNode};
+                for (uint32_t i = lane; i < n; i += 64) {
+                    double c[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k)
+                        c[k] = __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double d = sqrt(dist2<D>(c, q1, DIM));
+                    if (d < e.dist) { e.dist = d; e.idx = i; }
+                }
+                e = exact_wave_reduce(e);
+                nearest1 = uni(e.idx);
 #pragma unroll
                 for (int k = 0; k < D; ++k)
-                    c[k] = __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const double d = sqrt(dist2<D>(c, q1, DIM));
-                if (d < e.dist) { e.dist = d; e.idx = i; }
+                    q_near1[k] = unid(__hip_atomic_load(&tree[(size_t)k * cap + nearest1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const double dist1 = unid(e.dist);
+                dup1 = dist1 == 0.0;
+                steer<DIM>(p, true, dist1, q_near1, q1, qn1);
             }
-            e = exact_wave_reduce(e);
-            const uint32_t nearest1 = uni(e.idx);
-            double qn1[D], q_near1[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k)
-                q_near1[k] = unid(__hip_atomic_load(&tree[(size_t)k * cap + nearest1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const double dist1 = unid(e.dist);
-            const bool dup1 = dist1 == 0.0;
-            steer<DIM>(p, true, dist1, q_near1, q1, qn1);
             bool ok1 = true;
             if (nobs > 0) {
                 double mid1[D];
@@ -796,6 +957,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
             jr += 1;
             if (lane == 0) lds_post(&sh.resolved, jr);
+            if (STAMP) { uint64_t now = (uint64_t)clock64(); t_exact += now - t_e0; t_mark = now; }
             if (hit1 && p.stop_at_goal) { stop = 0; break; }
         }
     }
@@ -806,21 +968,22 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         st.stop_reason = stop;
         p.state[prob] = st;
         if (STAMP && p.dbg && prob == 0) {
-            p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict; p.dbg[1] = t_wait; p.dbg[2] = t_work;
+            p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_exact; p.dbg[15] = n_tie; p.dbg[11] = n_memo;
+            p.dbg[13] = (uint64_t)clock64() - t_begin; p.dbg[14] = (uint64_t)__builtin_amdgcn_s_memrealtime() - rt_begin;
         }
     }
 }
 
 #ifndef OXHIP_LANES_S
-#define OXHIP_LANES_S 21
-#define OXHIP_LANES_C 18
+#define OXHIP_LANES_S 24
+#define OXHIP_LANES_C 16
 #endif
-constexpr int kLS = OXHIP_LANES_S, kLC = OXHIP_LANES_C;   // register rows of the six heavy / of every scanner wave
+constexpr int kLS = OXHIP_LANES_S, kLC = OXHIP_LANES_C;   // register rows of the six heavy / of the two resolver-side scanner waves
 
 static int pick_slots_lanes(uint32_t cap) {
     const uint32_t need = (cap + kScanThreads - 1) / kScanThreads;
     if (need <= 4) return 4;
-    if (cap <= Layout<kLS, kLC, false>::kCapacity) return kLS;
+    if (cap <= Layout4<kLS, kLC>::kCapacity) return kLS;
     return 0;
 }
 

@@ -16,6 +16,11 @@ gpu.solve(10 ** 7)
 s = gpu.stamps()
 print("grow: kernel %.3f ms; problem 0: %d iterations in %d rounds (%.1f lanes offered, %.1f committed per round), %d conflict cuts, %d exact-path"
       % (gpu.last_timing()["kernel_ms"], int(s[7]), int(s[5]), int(s[6]) / max(1, int(s[5])), int(s[7]) / max(1, int(s[5])), int(s[12]), int(s[4])))
+itg = int(s[7])
+print("  resolver: wait %.0f  work %.0f cycles per iteration (%.0f per round); exact path %.0f per iteration (%.0f per event); lifetime %.3f ms at %.2f GHz"
+      % (int(s[1]) / itg, int(s[2]) / itg, int(s[2]) / max(1, int(s[5])), int(s[3]) / itg, int(s[3]) / max(1, int(s[4])), int(s[14]) / 1e5, int(s[13]) / max(1, int(s[14])) / 10.0))
+print("  scanner waves: wait", " ".join("%6.0f" % (int(v) / itg) for v in s[16:24]))
+print("                 work", " ".join("%6.0f" % (int(v) / itg) for v in s[24:32]))
 gpu.solve(iters, freeze=True)
 s2 = gpu.stamps()
 it = int(s2[7]) - int(s[7])
@@ -24,3 +29,6 @@ print("steady@10k: kernel %.3f ms (diagnostic build); problem 0: %d iterations i
 print("resolver: wait %.0f  work %.0f cycles per iteration (%.0f per round)" % (int(s2[1]) / it, int(s2[2]) / it, int(s2[2]) / max(1, int(s2[5]))))
 print("scanner waves: wait   ", " ".join("%6.0f" % (int(v) / it) for v in s2[16:24]))
 print("               work   ", " ".join("%6.0f" % (int(v) / it) for v in s2[24:32]))
+print("resolver lifetime: %d cycles in %.3f ms (100 MHz clock) = %.2f GHz; exact path %.0f cycles per iteration (%.0f per event)"
+      % (int(s2[13]), int(s2[14]) / 1e5, int(s2[13]) / max(1, int(s2[14])) / 10.0, int(s2[3]) / it, int(s2[3]) / max(1, int(s2[4]))))
+print("literal-loop (true near-tie) events: %d; whole-tree answers reused: %d" % (int(s2[15]), int(s2[11])))
