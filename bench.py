@@ -50,6 +50,20 @@ def valu_peak(kname):
     v_min_u32 per register row and query; 22 rows, two waves per SIMD as in the kernel) in (row, query) pairs per second,
     divided by the 160 rows of a 10,240-slot tree.  resident (binary64 scanners): tools/scan_bench.hip, 1.0 us per
     10k-node scan per CU (profiles/r1_resident)."""
+    if kname == "lanes":
+        # the dot-product screen: D packed fused multiply-adds per query pair + one v_min_f32 per query and 64-node register
+        # row (2.5 instructions per row and query), 24 rows, two waves per SIMD as in the kernel; a 10,000-node tree occupies
+        # 160 rows across the eight scanner waves (blocks of four rows)
+        try:
+            with open(os.path.join(ROOT, "profiles", "r2_valu_peak.json")) as f:
+                d = json.load(f)
+            for e in d["dot_screen"]:
+                if e["dim"] == 3 and e["rows"] == 24 and e["waves_per_simd"] == 2:
+                    return e["row_queries_per_s_chip"] / ROWS_PER_ITERATION, \
+                        "profiles/r2_valu_peak.json: dot_screen, R^3, 24 rows, 2 waves/SIMD, / 160 rows per iteration"
+        except (OSError, KeyError, ValueError):
+            pass
+        return None, "profiles/r2_valu_peak.json has no dot_screen entry"
     if kname == "resident_f32":
         try:
             with open(os.path.join(ROOT, "profiles", "r2_valu_peak.json")) as f:
@@ -152,7 +166,8 @@ def main():
     ap.add_argument("--strong-total", type=int, default=0,
                     help="strong scaling: this many problems in total, divided over the ranks (SURVEY.md 8(d): 8192)")
     ap.add_argument("--iters", type=int, default=4096, help="RRT iterations per problem per step")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident (binary64 scanners), 4 resident + binary32 screen")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident (binary64 scanners), 4 resident + binary32 screen (lane groups), "
+                                                          "5 resident + binary32 dot-product screen, lane-per-query resolver")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (stream kernel, all-binary64 resident kernel)")
     args = ap.parse_args()
@@ -194,6 +209,7 @@ def main():
     torch.cuda.synchronize()
     grow_s = time.perf_counter() - t0
     grow_t = gpu.last_timing()
+    grow_kname = KNAME[grow_t["kernel"]]
     c = gpu.counts()
     assert (c["nodes"] == N_NODES).all()
     grow_iters = int(c["iterations"].sum())
@@ -311,12 +327,12 @@ def main():
                        # checksum) is computed in f64 in the reference's evaluation order; the resident_f32 / stream kernels
                        # additionally SCREEN nearest-neighbour candidates in packed binary32 with a proven error bound and
                        # fall back to the f64 scan when the screen cannot decide -- bit-identical results
-                       "arithmetic": ("f64 results; packed-f32 candidate screen + f64 decision" if kname in ("resident_f32", "stream")
+                       "arithmetic": ("f64 results; packed-f32 candidate screen + f64 decision" if kname in ("resident_f32", "stream", "lanes")
                                       else "f64 throughout")},
             "roofline": roofline,
             "grow": {"iterations": float(allst[:, 4].sum()), "wall_s": float(allst[:, 5].max()),
                      "iterations_per_s": float(allst[:, 4].sum() / allst[:, 5].max()),
-                     "kernel_ms_rank0": float(allst[0, 6])},
+                     "kernel_ms_rank0": float(allst[0, 6]), "kernel": grow_kname},
             "per_rank": {"iterations_per_s_min": min(per_rank_its), "iterations_per_s_max": max(per_rank_its),
                          "step_time_skew": float(allst[:, 0].max() / allst[:, 0].min())},
         }

@@ -52,7 +52,8 @@ struct oxhip_rrt_batch {
     bool is_setup = false;
     double last_kernel_ms = 0.0;
     uint32_t last_launches = 0;
-    uint32_t kernel_kind = OXHIP_KERNEL_STREAM;
+    uint32_t kernel_kind = OXHIP_KERNEL_STREAM;   // the kind a launch uses (KERNEL_AUTO: resolved per launch, see solve)
+    uint32_t last_kind = OXHIP_KERNEL_STREAM;     // what the last launch ran
 };
 
 extern "C" {
@@ -190,7 +191,8 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     uint32_t kind = cfg->kernel;
     if (cfg->planner != OXHIP_PLANNER_RRT) kind = OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO)
-        kind = resident32_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT_F32
+        kind = lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES
+             : resident32_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT_F32
              : resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_PRUNED && !pruned_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
@@ -209,6 +211,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_BAD_ARG, "resident kernel does not support this (dim, max_nodes)");
     }
     b->kernel_kind = kind;
+    b->last_kind = kind;
     if ((cfg->planner == OXHIP_PLANNER_RRT && kind == OXHIP_KERNEL_STREAM) || cfg->planner == OXHIP_PLANNER_RRT_STAR) {
         // the streaming kernels screen their scans over an fl32 shadow of the tree, which they maintain themselves
         hipError_t e2 = b->tree32.alloc((size_t)P * dim * cap);
@@ -462,14 +465,22 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         uint64_t step = remaining < chunk ? remaining : chunk;
         b->dp.budget = step;
         b->dp.freeze = freeze ? 1 : 0;
+        // KERNEL_AUTO picks per launch among the register-resident kernels (they share every buffer): the lane-per-query
+        // kernel wherever it exists, except that growing R^2 / R^3 trees still runs faster on the lane-group resolver of
+        // rrt_resident32.hip
+        uint32_t kind = b->kernel_kind;
+        if (b->cfg.kernel == OXHIP_KERNEL_AUTO && kind == OXHIP_KERNEL_LANES && !freeze &&
+            resident32_supported(b->cfg.dim, b->dp.cap))
+            kind = OXHIP_KERNEL_RESIDENT_F32;
+        b->last_kind = kind;
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
         if (b->cfg.space == OXHIP_SPACE_SE2) launch_rrt_connect_se2(b->dp, b->stream);
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) launch_rrt_star(b->dp, b->stream);
-        else if (b->kernel_kind == OXHIP_KERNEL_PRUNED) launch_rrt_pruned(b->dp, b->stream);
-        else if (b->kernel_kind == OXHIP_KERNEL_LANES) launch_rrt_lanes(b->dp, b->stream);
-        else if (b->kernel_kind == OXHIP_KERNEL_RESIDENT_F32) launch_rrt_resident32(b->dp, b->stream);
-        else if (b->kernel_kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
+        else if (kind == OXHIP_KERNEL_PRUNED) launch_rrt_pruned(b->dp, b->stream);
+        else if (kind == OXHIP_KERNEL_LANES) launch_rrt_lanes(b->dp, b->stream);
+        else if (kind == OXHIP_KERNEL_RESIDENT_F32) launch_rrt_resident32(b->dp, b->stream);
+        else if (kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
         else launch_rrt_stream(b->dp, b->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -670,7 +681,7 @@ int32_t oxhip_rrt_batch_last_timing(oxhip_rrt_batch* b, double* kernel_ms, uint3
     if (!b) return fail(OXHIP_ERR_BAD_ARG, "null batch");
     if (kernel_ms) *kernel_ms = b->last_kernel_ms;
     if (launches) *launches = b->last_launches;
-    if (kernel_kind) *kernel_kind = b->kernel_kind;
+    if (kernel_kind) *kernel_kind = b->cfg.planner == OXHIP_PLANNER_RRT ? b->last_kind : b->kernel_kind;
     return OXHIP_OK;
 }
 

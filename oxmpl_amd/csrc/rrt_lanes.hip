@@ -45,7 +45,7 @@ typedef float lf32x2 __attribute__((ext_vector_type(2)));
 constexpr int kLanesThreads = kScanThreads + 128;   // + the resolver wave + the sampler wave
 constexpr int kQRing = 128;                         // queries in flight (power of two)
 constexpr int kNRing = 256;                         // committed nodes kept in LDS (power of two, >= kQRing + 64)
-constexpr int kPassQ = 8;                           // queries one scanner pass covers
+template <int DIM> struct LanesPass { static constexpr int Q = DIM >= 6 ? 4 : 8; };   // queries one scanner pass covers (register budget)
 constexpr uint32_t kDepthGrow = 96;                 // queries sampled ahead of the resolver while inserts are on
 #ifndef OXHIP_LANES_PRIO
 #define OXHIP_LANES_PRIO 16
@@ -101,7 +101,7 @@ struct LanesShared {
     uint32_t rng_buf[16][64];
     double q[DIM][kQRing];               // the queries, coordinate-major: resolver lane j reads q[k][slot_j] conflict-free
     uint64_t pos_after[kQRing];          // stream position after each query's draws
-    float qf[kQRing][4];                 // Q = -2 fl32(q - c0): what the scanners screen with (one 16-byte uniform read per query)
+    float qf[kQRing][DIM <= 4 ? 4 : 8];  // Q = -2 fl32(q - c0): what the scanners screen with (one or two 16-byte uniform reads per query)
     LanePub pub[kScanWaves][kQRing];     // wave-major: resolver lane j reads pub[w][slot_j] conflict-free
     double newn[DIM][kNRing];            // the last kNRing committed nodes, node i at i & (kNRing - 1); +inf for skipped duplicates
     double obs[DIM + 2][64];             // first 64 spheres: centre, validity threshold, filter threshold
@@ -249,7 +249,8 @@ __device__ __forceinline__ void absorb_row(lf32x2 (&tr)[DIM][S / 2], lf32x2 (&tc
 template <int DIM, int S, int C, bool STAMP>
 __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     constexpr int D = DIM;
-    static_assert(DIM <= 4, "qf holds four floats per query");
+    constexpr int kPassQ = LanesPass<DIM>::Q;
+    static_assert(DIM <= 8, "qf holds eight floats per query");
     using Lay = Layout4<S, C>;
 
     const uint32_t prob = blockIdx.x;
@@ -469,13 +470,13 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                     spins = 0;
                 }
                 jr_seen = uni(lds_peek(&sh.resolved));
-                if (js - jr_seen + 16u <= depth) { go = true; break; }   // two scanner passes' worth of the window is free: refill it
+                if (js - jr_seen + 2u * (uint32_t)kPassQ <= depth) { go = true; break; }   // two scanner passes' worth of the window is free: refill it
                 __builtin_amdgcn_s_sleep(2);
             }
             if (!go) break;  // stop requested (or a protocol bug: the resolver's own guard reports it)
             uint32_t m = jr_seen + depth - js;  // free window slots
             if (m > 64u) m = 64u;
-            if (m > 8u) m -= (js + m) & 7u;     // the scanners consume whole passes of 8: end the batch on a pass boundary
+            if (m > (uint32_t)kPassQ) m -= (js + m) & (uint32_t)(kPassQ - 1);     // the scanners consume whole passes: end the batch on a pass boundary
             if (m > budget - js) m = budget - js;
             // keep the batch's words inside the LDS window: refill (64 blocks from the current position) when short
             const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + D) + 64;
@@ -586,7 +587,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 // never wait for more than the scanners are going to publish without further sampling: whole passes of 8
                 // of what has been sampled (the sampler refills by its own rule and may be waiting for this wave)
                 const uint32_t sampled_now = uni(lds_peek(&sh.sampled));
-                const uint32_t coming = (sampled_now >= budget ? budget : (sampled_now & ~7u)) - jr;
+                const uint32_t coming = (sampled_now >= budget ? budget : (sampled_now & ~(uint32_t)(kPassQ - 1))) - jr;
                 uint32_t want = depth / 2;
                 if (want > coming) want = coming;
                 const uint32_t d = lane < (uint32_t)kScanWaves ? lds_peek(&sh.wave_done[lane & (kScanWaves - 1)]) : 0xFFFFFFFFu;
@@ -643,18 +644,22 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             const bool have = act && ib < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
             if (__ballot(have) == 0) continue;       // a small tree fills the first blocks only
             const uint32_t il = have ? ib : 0u;
-            ldouble4 c4[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k) c4[k] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il);
             const uint32_t sk4 = *reinterpret_cast<const uint32_t*>(skip + il);
+            // the reference's sum, coordinate by coordinate (0.0 + x*x == x*x, then + y*y, ...): four nodes' sums side by side
+            double d4[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                double c[D];
+            for (int k = 0; k < D; ++k) {
+                const ldouble4 ck = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il);
 #pragma unroll
-                for (int k = 0; k < D; ++k) c[k] = c4[k][t];
-                const double d = dist2<D>(c, q, DIM);
-                if (have && ib + (uint32_t)t < bmin && ((sk4 >> (8 * t)) & 0xFFu) == 0) scan_push(pd, d, ib + (uint32_t)t);
+                for (int t = 0; t < 4; ++t) {
+                    const double df = ck[t] - q[k];
+                    const double sq = df * df;
+                    d4[t] = k == 0 ? sq : d4[t] + sq;
+                }
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (have && ib + (uint32_t)t < bmin && ((sk4 >> (8 * t)) & 0xFFu) == 0) scan_push(pd, d4[t], ib + (uint32_t)t);
         }
         {
             const uint32_t lo = wave_min_u32(act ? bmin : 0xFFFFFFFFu);
@@ -698,18 +703,19 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             lerp<DIM>(q_near, qn, 0.5, mid, DIM);
             // (eight spheres per trip: their LDS reads -- wave-uniform addresses, broadcast -- are issued together, so the
             // loop runs at the arithmetic's pace instead of one LDS round trip per sphere; slots beyond ns64 hold -1 thresholds)
+            constexpr int U = DIM <= 3 ? 8 : 4;   // spheres per trip (registers: U x (DIM + 1) doubles)
             uint32_t maybe_lo = 0, maybe_hi = 0;
-            for (uint32_t o0 = 0; o0 < ns64; o0 += 8) {
-                double c[8][D], f[8];
+            for (uint32_t o0 = 0; o0 < ns64; o0 += U) {
+                double c[U][D], f[U];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < U; ++t) {
 #pragma unroll
                     for (int k = 0; k < D; ++k) c[t][k] = sh.obs[k][o0 + t];
                     f[t] = sh.obs[D + 1][o0 + t];
                 }
                 uint32_t bits = 0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) bits |= sphere_maybe_hit<DIM>(c[t], f[t], mid) ? (1u << t) : 0u;
+                for (int t = 0; t < U; ++t) bits |= sphere_maybe_hit<DIM>(c[t], f[t], mid) ? (1u << t) : 0u;
                 if (o0 < 32) maybe_lo |= bits << o0; else maybe_hi |= bits << (o0 - 32);
             }
             const uint64_t maybe = ((uint64_t)maybe_hi << 32) | maybe_lo;
@@ -859,25 +865,35 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 // a lane takes four consecutive nodes per 32-byte load and coordinate, four such groups per trip: 16 nodes per
                 // lane in flight (the trees of a whole batch do not fit the L2: a trip is a DRAM / Infinity Cache round trip)
                 for (uint32_t i0 = 4u * lane; i0 < n; i0 += 1024u) {
-                    ldouble4 c4[4][D];
-                    uint32_t sk4[4];
+                    uint32_t sk4[4], il[4];
+                    double d16[4][4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const uint32_t ib = i0 + 256u * (uint32_t)t, il = ib < n ? ib : 0u;   // (rows are padded to cap >= n rounded up to 1024)
+                        const uint32_t ib = i0 + 256u * (uint32_t)t;
+                        il[t] = ib < n ? ib : 0u;   // (rows are padded to cap >= n rounded up to 1024)
+                        sk4[t] = *reinterpret_cast<const uint32_t*>(skip + il[t]);
+                    }
 #pragma unroll
-                        for (int k = 0; k < D; ++k) c4[t][k] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il);
-                        sk4[t] = *reinterpret_cast<const uint32_t*>(skip + il);
+                    for (int k = 0; k < D; ++k) {
+                        ldouble4 ck[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) ck[t] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il[t]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double df = ck[t][r] - q1[k];
+                                const double sq = df * df;
+                                d16[t][r] = k == 0 ? sq : d16[t][r] + sq;   // the reference's summation order
+                            }
+                        }
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const uint32_t i = i0 + 256u * (uint32_t)t + (uint32_t)r;
-                            double c[D];
-#pragma unroll
-                            for (int k = 0; k < D; ++k) c[k] = c4[t][k][r];
-                            const double d = dist2<D>(c, q1, DIM);
-                            if (i < n && ((sk4[t] >> (8 * r)) & 0xFFu) == 0) scan_push(ps, d, i);   // ascending within the lane: ties keep the lower index
+                            if (i < n && ((sk4[t] >> (8 * r)) & 0xFFu) == 0) scan_push(ps, d16[t][r], i);   // ascending within the lane: ties keep the lower index
                         }
                     }
                 }
@@ -978,31 +994,56 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #define OXHIP_LANES_S 24
 #define OXHIP_LANES_C 16
 #endif
-constexpr int kLS = OXHIP_LANES_S, kLC = OXHIP_LANES_C;   // register rows of the six heavy / of the two resolver-side scanner waves
+constexpr int kLS = OXHIP_LANES_S, kLC = OXHIP_LANES_C;   // register rows of the six heavy / of the two resolver-side scanner waves (R^2, R^3)
+// R^4 .. R^6: a row costs DIM + 1 registers, so the rows are spread evenly (20 x 512 = 10,240 nodes); R^2 / R^3 also have a
+// 40 / 32-row instantiation for trees of up to 20,480 / 16,384 nodes
+template <int DIM> struct LanesShape { static constexpr int S = 20, C = 20, SB = 0, CB = 0; };
+template <> struct LanesShape<2> { static constexpr int S = kLS, C = kLC, SB = 40, CB = 40; };
+template <> struct LanesShape<3> { static constexpr int S = kLS, C = kLC, SB = 32, CB = 32; };
 
-static int pick_slots_lanes(uint32_t cap) {
-    const uint32_t need = (cap + kScanThreads - 1) / kScanThreads;
-    if (need <= 4) return 4;
-    if (cap <= Layout4<kLS, kLC>::kCapacity) return kLS;
+template <int DIM>
+static int pick_rows_lanes(uint32_t cap) {
+    if (cap <= 2048u) return 4;
+    if (cap <= Layout4<LanesShape<DIM>::S, LanesShape<DIM>::C>::kCapacity) return LanesShape<DIM>::S;
+    if (LanesShape<DIM>::SB != 0 && cap <= Layout4<LanesShape<DIM>::SB ? LanesShape<DIM>::SB : 4, LanesShape<DIM>::SB ? LanesShape<DIM>::CB : 4>::kCapacity)
+        return LanesShape<DIM>::SB;
     return 0;
 }
 
-bool lanes_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && pick_slots_lanes(cap) != 0; }
+bool lanes_supported(uint32_t dim, uint32_t cap) {
+    switch (dim) {
+        case 2: return pick_rows_lanes<2>(cap) != 0;
+        case 3: return pick_rows_lanes<3>(cap) != 0;
+        case 4: return pick_rows_lanes<4>(cap) != 0;
+        case 5: return pick_rows_lanes<5>(cap) != 0;
+        case 6: return pick_rows_lanes<6>(cap) != 0;
+        default: return false;
+    }
+}
+
+template <int DIM, int S, int C>
+static void launch_lanes_shape(const DevParams& p, hipStream_t stream) {
+    dim3 grid(p.n_problems), block(kLanesThreads);
+    if (p.dbg) hipLaunchKernelGGL((rrt_lanes_kernel<DIM, S, C, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((rrt_lanes_kernel<DIM, S, C, false>), grid, block, 0, stream, p);
+}
+template <int DIM>
+static void launch_lanes_dim(const DevParams& p, hipStream_t stream) {
+    const int s = pick_rows_lanes<DIM>(p.cap);
+    if (s == 4) launch_lanes_shape<DIM, 4, 4>(p, stream);
+    else if (s == LanesShape<DIM>::S) launch_lanes_shape<DIM, LanesShape<DIM>::S, LanesShape<DIM>::C>(p, stream);
+    else if constexpr (LanesShape<DIM>::SB != 0) launch_lanes_shape<DIM, LanesShape<DIM>::SB, LanesShape<DIM>::CB>(p, stream);
+}
 
 void launch_rrt_lanes(const DevParams& p, hipStream_t stream) {
-    dim3 grid(p.n_problems), block(kLanesThreads);
-    const int s = pick_slots_lanes(p.cap);
-#define OXHIP_LAUNCH(DIM_, S_, C_)                                                                            \
-    do {                                                                                                      \
-        if (p.dbg) hipLaunchKernelGGL((rrt_lanes_kernel<DIM_, S_, C_, true>), grid, block, 0, stream, p);     \
-        else hipLaunchKernelGGL((rrt_lanes_kernel<DIM_, S_, C_, false>), grid, block, 0, stream, p);          \
-    } while (0)
-    if (p.dim == 3) {
-        if (s == 4) OXHIP_LAUNCH(3, 4, 4); else OXHIP_LAUNCH(3, kLS, kLC);
-    } else {
-        if (s == 4) OXHIP_LAUNCH(2, 4, 4); else OXHIP_LAUNCH(2, kLS, kLC);
+    switch (p.dim) {
+        case 2: launch_lanes_dim<2>(p, stream); break;
+        case 3: launch_lanes_dim<3>(p, stream); break;
+        case 4: launch_lanes_dim<4>(p, stream); break;
+        case 5: launch_lanes_dim<5>(p, stream); break;
+        case 6: launch_lanes_dim<6>(p, stream); break;
+        default: break;
     }
-#undef OXHIP_LAUNCH
 }
 
 }  // namespace oxhip

@@ -17,9 +17,10 @@ pytestmark = pytest.mark.gpu
 from oxmpl_amd import capi, scenarios  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
 
-KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES]   # KERNEL_PRUNED: experiment, not in the product build
+# KERNEL_AUTO switches kernels between launches (grow: resident_f32, frozen: lanes); KERNEL_PRUNED is an experiment, not in the product build
+KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES, capi.KERNEL_AUTO]
 KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_PRUNED: "pruned",
-         capi.KERNEL_RESIDENT_F32: "resident_f32", capi.KERNEL_LANES: "lanes"}
+         capi.KERNEL_RESIDENT_F32: "resident_f32", capi.KERNEL_LANES: "lanes", capi.KERNEL_AUTO: "auto"}
 SCREENED = (capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES)   # kernels that count their exact-path events (stamps()[4])
 
 
@@ -286,7 +287,7 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
     """dims 1..6, spheres+boxes mixed, goal_bias 0 / 1 / 0.5, more obstacles than one wave."""
     rng = np.random.default_rng(21)
     for dim, gb, ns, nb in [(1, 0.05, 0, 0), (2, 0.5, 3, 2), (3, 1.0, 70, 0), (3, 0.0, 130, 5), (4, 0.1, 10, 1),
-                            (6, 0.05, 20, 0)]:
+                            (5, 0.3, 40, 2), (6, 0.05, 20, 0)]:
         bounds = [(-3.0, 7.0)] * dim
         sc = dict(dim=dim, bounds=bounds, max_distance=0.7, goal_bias=gb, lvs_fraction=0.02,
                   start=[-2.5] * dim, goal_centre=[6.5] * dim, goal_radius=0.4,
@@ -296,8 +297,10 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
             lo = rng.random((nb, dim)) * 6.0 - 1.0
             sc["boxes"] = (lo, lo + rng.random((nb, dim)) * 0.8 + 0.1)
         P = 6
-        if kernel in (capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED, capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES) and dim not in (2, 3):
-            continue  # the resident kernel is instantiated for R^2 / R^3 only
+        if kernel in (capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED, capi.KERNEL_RESIDENT_F32) and dim not in (2, 3):
+            continue  # these resident kernels are instantiated for R^2 / R^3 only
+        if kernel == capi.KERNEL_LANES and dim not in (2, 3, 4, 5, 6):
+            continue  # the lane-per-query kernel: R^2 .. R^6
         gpu = _gpu_for(sc, P, 400, False, 7, 100, kernel)
         gpu.solve(500)
         planners = [_oracle_for(sc, 7, 100 + p, 400, False) for p in range(P)]

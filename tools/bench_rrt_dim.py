@@ -21,7 +21,7 @@ sc = dict(dim=dim, bounds=[(0.0, 10.0)] * dim, max_distance=1.0, goal_bias=0.05,
           start=[1.0] * dim, goal_centre=[9.0] * dim, goal_radius=1.0,
           spheres=(np.ascontiguousarray(np.hstack([c, np.full((len(c), max(0, dim - 6)), 5.0)])[:, :dim]), r * (0.45 if dim < 6 else 1.0)),
           boxes=None)
-g = scenarios.make_batch(sc, P, nodes, False, 42, 0, 0, 0)
+g = scenarios.make_batch(sc, P, nodes, False, 42, 0, 0, int(os.environ.get("OXHIP_KERNEL", "0")))
 g.solve(10 ** 8)
 t = g.last_timing()
 cts = g.counts()
@@ -35,7 +35,7 @@ for _ in range(3):
     ms += g.last_timing()["kernel_ms"]
 ms /= 3
 its = P * iters / (ms * 1e-3)
-print(json.dumps({"planner": "RRT", "dim": dim, "problems": P, "nodes": nodes, "kernel": {1: "stream", 2: "resident", 3: "pruned", 4: "resident_f32"}[t["kernel"]],
+print(json.dumps({"planner": "RRT", "dim": dim, "problems": P, "nodes": nodes, "kernel": {1: "stream", 2: "resident", 3: "pruned", 4: "resident_f32", 5: "lanes"}[g.last_timing()["kernel"]],
                   "grow_iterations_per_s": grow_its / (grow_ms * 1e-3), "grow_kernel_ms": grow_ms,
                   "steady_iterations_per_s": its, "steady_kernel_ms": ms,
                   "roofline": {"bound": "hbm", "achieved": its * nodes * dim * 8 / 1e9, "peak": 8000.0, "unit": "GB/s",

@@ -15,5 +15,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 benc
 echo write done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 2 --warmup 1 $ARGS > /dev/null 2> $OUT/pmc_sq.err
 echo sq done
-if [ -z "$2" ]; then python3 tools/stamps.py 1024 4096 0 > $OUT/inkernel_stamps.txt 2>&1; else echo "(stamps exist for the resident kernels only)" > $OUT/inkernel_stamps.txt; fi
+if [ -z "$2" ]; then python3 tools/stamps_lanes.py 1024 4096 > $OUT/inkernel_stamps.txt 2>&1; else echo "(stamps: tools/stamps.py / tools/stamps_lanes.py for the resident kernels)" > $OUT/inkernel_stamps.txt; fi
 find $OUT -name "*.csv" | head -30

@@ -208,6 +208,67 @@ __global__ __launch_bounds__(NT) void screen_kernel(const float* pts, uint64_t* 
     if (fold == 0x1234567) sink[0] = fold;
 }
 
+// ---- the dot-product screen of rrt_lanes.hip: a node is (a, cc = |a|^2), a query Q = -2 b, s' = cc + a . Q: D packed fused
+// multiply-adds per (row, query pair) and one v_min_f32 per (row, query) -- 2.5 instructions per (row, query) in R^3
+template <int S, int D, int NQ, int NT>
+__global__ __launch_bounds__(NT) void dot_kernel(const float* pts, uint64_t* cyc, uint32_t* sink, int iters) {
+    static_assert(S % 2 == 0, "rows are held two per register pair");
+    extern __shared__ char pad[];
+    float (*qring)[8] = reinterpret_cast<float (*)[8]>(pad);   // 64 queries
+    f32x2 tr[D][S / 2], tcc[S / 2];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        float sq = 0.f;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { const float f = pts[((size_t)(threadIdx.x + NT * s) % 16384) * 8 + k] - 5.0f; tr[k][s / 2][s % 2] = f; sq += f * f; }
+        tcc[s / 2][s % 2] = sq;
+    }
+    if (threadIdx.x < 64)
+        for (int k = 0; k < 8; ++k) qring[threadIdx.x][k] = -2.0f * (-4.0f + 0.125f * (float)((threadIdx.x * 7 + k * 13 + blockIdx.x) % 64));
+    __syncthreads();
+    float b1[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) b1[b] = __builtin_inff();
+    uint32_t fold = 0;
+    const uint64_t t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < S / 2; ++s) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) asm volatile("" : "+v"(tr[k][s]));
+            asm volatile("" : "+v"(tcc[s]));
+        }
+        f32x2 q[NQ / 2][D];
+#pragma unroll
+        for (int b = 0; b < NQ; ++b)
+#pragma unroll
+            for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = bits_f32(uni(f32_bits(qring[(it * NQ + b) & 63][k])));
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            f32x2 acc[NQ / 2];
+#pragma unroll
+            for (int bp = 0; bp < NQ / 2; ++bp)
+                acc[bp] = (s & 1) ? __builtin_shufflevector(tcc[s / 2], tcc[s / 2], 1, 1) : __builtin_shufflevector(tcc[s / 2], tcc[s / 2], 0, 0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const f32x2 a = (s & 1) ? __builtin_shufflevector(tr[k][s / 2], tr[k][s / 2], 1, 1) : __builtin_shufflevector(tr[k][s / 2], tr[k][s / 2], 0, 0);
+#pragma unroll
+                for (int bp = 0; bp < NQ / 2; ++bp) acc[bp] = __builtin_elementwise_fma(a, q[bp][k], acc[bp]);
+            }
+#pragma unroll
+            for (int bp = 0; bp < NQ / 2; ++bp) {
+                asm("v_min_f32 %0, %0, %1" : "+v"(b1[2 * bp]) : "v"(acc[bp][0]));
+                asm("v_min_f32 %0, %0, %1" : "+v"(b1[2 * bp + 1]) : "v"(acc[bp][1]));
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) { fold ^= f32_bits(b1[b]); b1[b] = __builtin_inff(); }
+    }
+    const uint64_t t1 = clock64();
+    if (threadIdx.x % 64 == 0) cyc[blockIdx.x * (NT / 64) + threadIdx.x / 64] = t1 - t0;
+    if (fold == 0x1234567) sink[0] = fold;
+}
+
 struct Result { double ns_per_inst_simd, cyc_median_per_inst_simd, wall_ms, clk_ghz_1w; };
 
 static int n_cu = 256;
@@ -308,6 +369,21 @@ int main() {
     RUN_SCREEN(22, 3, 2, 1); RUN_SCREEN(22, 3, 3, 1); RUN_SCREEN(22, 3, 2, 2); RUN_SCREEN(22, 3, 3, 2); RUN_SCREEN(22, 3, 2, 3);
     RUN_SCREEN(40, 3, 2, 1); RUN_SCREEN(40, 3, 3, 1); RUN_SCREEN(40, 3, 2, 2); RUN_SCREEN(40, 3, 3, 2);
     RUN_SCREEN(20, 6, 2, 1); RUN_SCREEN(20, 4, 2, 1); RUN_SCREEN(20, 4, 3, 1);
+    printf("\n ],\n \"dot_screen\": [\n");
+    first = true;
+#define RUN_DOT(S_, D_, W_)                                                                                        \
+    do {                                                                                                          \
+        Result r;                                                                                                 \
+        const int it = 3000;                                                                                      \
+        auto L = [&](int n) { hipLaunchKernelGGL((dot_kernel<S_, D_, 8, 256 * W_>), dim3(n_cu), dim3(256 * W_), kLdsPad, 0, d_pts, d_cyc, d_sink, n); }; \
+        if (run(L, W_, it, (double)(S_) * 8.0, r, d_cyc, h_cyc)) return 1;                                        \
+        const double rq_per_s_chip = (double)n_cu * 4 * W_ * (double)(S_) * 8.0 * it / (r.wall_ms * 1e-3);       \
+        printf("%s  {\"rows\": %d, \"dim\": %d, \"waves_per_simd\": %d, \"ns_per_row_query_per_simd\": %.4f, \"wall_ms\": %.3f, " \
+               "\"row_queries_per_s_chip\": %.4e}", first ? "" : ",\n", S_, D_, W_, r.ns_per_inst_simd, r.wall_ms, rq_per_s_chip); \
+        first = false;                                                                                            \
+    } while (0)
+    RUN_DOT(24, 3, 1); RUN_DOT(24, 3, 2); RUN_DOT(24, 3, 3); RUN_DOT(16, 3, 2);
+    RUN_DOT(24, 2, 2); RUN_DOT(20, 4, 2); RUN_DOT(20, 5, 2); RUN_DOT(16, 6, 2);
     printf("\n ]}\n");
     return 0;
 }
