@@ -200,7 +200,7 @@ int32_t oxhip_rrt_batch_last_timing(oxhip_rrt_batch* b, double* kernel_ms, uint3
  * {0 scan+publish, 1 barrier-1 wait, 2 resolve, 3 -, 4 motion check / next sample, 5 barrier-3 wait,
  *  6 verdict+insert, 7 iterations}; out[16+w]: wave w's summed (barrier-1 arrival - barrier-3 release). */
 int32_t oxhip_rrt_batch_enable_stamps(oxhip_rrt_batch* b, uint32_t enable);
-int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out /*[32]*/);
+int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out /*[64]*/);
 
 /* ---- stand-alone batched primitives (same device functions as the planner kernels) ---- */
 

@@ -303,7 +303,7 @@ class RRTBatch:
         _check(lib().oxhip_rrt_batch_enable_stamps(self._h, int(bool(enable))))
 
     def stamps(self):
-        out = np.zeros(32, dtype=np.uint64)
+        out = np.zeros(64, dtype=np.uint64)
         _check(lib().oxhip_rrt_batch_get_stamps(self._h, _p(out, _u64p)))
         return out
 

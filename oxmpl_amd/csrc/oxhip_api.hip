@@ -690,8 +690,8 @@ int32_t oxhip_rrt_batch_enable_stamps(oxhip_rrt_batch* b, uint32_t enable) {
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
     if (enable) {
-        HIP_TRY(b->dbg.alloc(32));
-        HIP_TRY(hipMemsetAsync(b->dbg.p, 0, 32 * sizeof(uint64_t), b->stream));
+        HIP_TRY(b->dbg.alloc(64));
+        HIP_TRY(hipMemsetAsync(b->dbg.p, 0, 64 * sizeof(uint64_t), b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
         b->dp.dbg = b->dbg.p;
     } else {
@@ -705,7 +705,7 @@ int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out) {
     if (!b->dp.dbg) return fail(OXHIP_ERR_BAD_ARG, "stamps are not enabled");
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
-    HIP_TRY(hipMemcpyAsync(out, b->dbg.p, 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(out, b->dbg.p, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return OXHIP_OK;
 }

@@ -46,7 +46,10 @@ constexpr int kLanesThreads = kScanThreads + 128;   // + the resolver wave + the
 constexpr int kQRing = 128;                         // queries in flight (power of two)
 constexpr int kNRing = 256;                         // committed nodes kept in LDS (power of two, >= kQRing + 64)
 template <int DIM> struct LanesPass { static constexpr int Q = DIM >= 6 ? 4 : 8; };   // queries one scanner pass covers (register budget)
-constexpr uint32_t kDepthGrow = 96;                 // queries sampled ahead of the resolver while inserts are on
+#ifndef OXHIP_DEPTH_GROW
+#define OXHIP_DEPTH_GROW 96
+#endif
+constexpr uint32_t kDepthGrow = OXHIP_DEPTH_GROW;                 // queries sampled ahead of the resolver while inserts are on
 #ifndef OXHIP_LANES_PRIO
 #define OXHIP_LANES_PRIO 16
 #endif
@@ -105,6 +108,9 @@ struct LanesShared {
     LanePub pub[kScanWaves][kQRing];     // wave-major: resolver lane j reads pub[w][slot_j] conflict-free
     double newn[DIM][kNRing];            // the last kNRing committed nodes, node i at i & (kNRing - 1); +inf for skipped duplicates
     double obs[DIM + 2][64];             // first 64 spheres: centre, validity threshold, filter threshold
+    float newn32[kNRing][DIM < 4 ? 4 : 8];   // the same nodes as the scanners hold them: a = fl32(x - c0), then cc = fl32(|a|^2) (+inf: skipped)
+    float obs32[64][DIM < 4 ? 4 : 8];        // the spheres for the binary32 pre-filter: fl32(centre - c0), then fl32(|.|^2)
+    float obs32_thr[64];                     // ... and the filter threshold + error bound, rounded up (-1: no sphere)
     uint32_t wave_done[kScanWaves];      // queries each scanner wave has published (monotonic)
     uint32_t sampled, resolved, committed, stop_flag;
     uint32_t heartbeat;                  // bumped by the resolver while it works: waiters only give up when it stands still
@@ -160,6 +166,15 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63));
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return ~wave_min_u32(~v); }
+__device__ __forceinline__ double wave_max_f64pos(double v) {   // v >= +0 (or NaN -> treated as huge): bit patterns order like values
+    const uint32_t hi = wave_max_u32((uint32_t)__double2hiint(v));
+    const uint32_t lo = wave_max_u32((uint32_t)__double2hiint(v) == hi ? (uint32_t)__double2loint(v) : 0u);
+    return __hiloint2double((int)hi, (int)lo);
+}
+__device__ __forceinline__ float f32_up(double x) {   // a binary32 value >= x (two ulps of slack; NaN stays NaN, +inf stays +inf)
+    const float t = (float)x;
+    return t + fabsf(t) * 0x1p-22f + 1e-37f;
+}
 
 __device__ __forceinline__ uint64_t below_mask(uint32_t lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ uint64_t first_n_mask(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
@@ -348,15 +363,10 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 Lay::locate(i, owner_thread, sl);
                 if ((owner_thread >> 6) != wave) continue;   // another wave's node: skip the row ladder below
                 const bool mine = tid == owner_thread;
-                float f[D];
-                double sq = 0.0;
-                const bool dupn = !(sh.newn[0][i & (kNRing - 1)] < __builtin_inf());   // the ring holds +inf for a skipped duplicate
+                float f[D];   // the resolver wrote the node as the scanners hold it: a = fl32(x - c0), cc = fl32(|a|^2) (+inf: skipped duplicate)
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    f[k] = dupn ? 0.0f : (float)(sh.newn[k][i & (kNRing - 1)] - c0[k]);
-                    sq += (double)f[k] * (double)f[k];
-                }
-                const float fcc = dupn ? __builtin_inff() : (float)sq;
+                for (int k = 0; k < D; ++k) f[k] = sh.newn32[i & (kNRing - 1)][k];
+                const float fcc = sh.newn32[i & (kNRing - 1)][D];
                 // (register arrays cannot be indexed dynamically: the wave-uniform row number selects one of S compile-time copies)
                 absorb_row<DIM, S>(tr, tcc, uni(sl), mine, f, fcc);
             }
@@ -546,7 +556,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     uint32_t n = st.n_nodes;
     uint32_t jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
-    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
+    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = STAMP ? (uint64_t)clock64() : 0;
     const uint64_t t_begin = t_mark, rt_begin = STAMP ? (uint64_t)__builtin_amdgcn_s_memrealtime() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
@@ -563,6 +573,24 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         const double u = 0x1p-24;
         mg.usable = h < 1e15 && fabs(c0[0]) < 1e300;  // also false for NaN / inf
         mg.e2 = 2.0 * (u * h * h * (double)(D * (3 * D + 9)) * 1.0001 + 1e-290);
+        // the spheres for the binary32 pre-filter of the motion check: same error model with H_f = max(H, |centre - c0|)
+        double hs = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) hs = fmax(hs, lane < ns64 ? fabs(oc[k] - c0[k]) : 0.0);
+        const double hf = fmax(h, wave_max_f64pos(hs));
+        const double ef = 2.0 * (u * hf * hf * (double)(D * (3 * D + 9)) * 1.0001 + 1e-290);
+        double sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float f = (float)(oc[k] - c0[k]);
+            sh.obs32[lane][k] = f;
+            sq += (double)f * (double)f;
+        }
+        sh.obs32[lane][D] = (float)sq;
+        // a sphere is cleared when s' + |m|^2 > thr: thr = (filter threshold + 2 E_f), rounded up (and two ulps more for the sum)
+        float thr = (float)((ofilt + ef) * (1.0 + 0x1p-21));
+        thr = thr + fabsf(thr) * 0x1p-22f;
+        sh.obs32_thr[lane] = (lane < ns64 && mg.usable && hf < 1e15 && ofilt >= 0.0) ? thr : (lane < ns64 ? __builtin_inff() : -1.0f);
     }
 
     typedef double ldouble4 __attribute__((ext_vector_type(4)));
@@ -572,6 +600,8 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
     for (int k = 0; k < D; ++k) memo_q[k] = 0.0;
 
+    uint64_t t_pm = 0;
+#define OXHIP_PHASE(IDX) do { if (STAMP) { const uint64_t now_ = (uint64_t)clock64(); t_ph[IDX] += now_ - t_pm; t_pm = now_; } } while (0)
     while (true) {
         if (jr >= budget) { stop = 1; break; }
         if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
@@ -605,6 +635,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         if (STAMP) { ++n_rounds; n_lanes += m; uint64_t now = (uint64_t)clock64(); t_wait += now - t_mark; t_mark = now; }
 
         // ---- parallel phase: lane j resolves query jr + j against the tree of n nodes
+        if (STAMP) t_pm = (uint64_t)clock64();
         const bool act = lane < m;
         const uint32_t slot = (jr + (act ? lane : 0u)) & (kQRing - 1);
         double q[D];
@@ -638,51 +669,94 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         // the winning scanner lane's own nodes, in binary64 from the tree (four consecutive nodes per block of rows), then
         // the nodes committed after the oldest snapshot, from the LDS ring: ascending indices, so ties keep the lower index
         Scan pd{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
+        // (two blocks per trip: the tree of a whole batch does not fit the L2, a trip is a memory round trip)
 #pragma unroll
-        for (int blk = 0; blk < S / 4; ++blk) {
-            const uint32_t ib = Lay::block_base(wth, (uint32_t)blk);
-            const bool have = act && ib < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
-            if (__ballot(have) == 0) continue;       // a small tree fills the first blocks only
-            const uint32_t il = have ? ib : 0u;
-            const uint32_t sk4 = *reinterpret_cast<const uint32_t*>(skip + il);
-            // the reference's sum, coordinate by coordinate (0.0 + x*x == x*x, then + y*y, ...): four nodes' sums side by side
-            double d4[4];
+        for (int blk0 = 0; blk0 < S / 4; blk0 += 2) {
+            uint32_t ib2[2], il2[2], sk2[2];
+            bool have2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ib2[h] = blk0 + h < S / 4 ? Lay::block_base(wth, (uint32_t)(blk0 + h)) : kNoNode;
+                have2[h] = act && ib2[h] < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
+                il2[h] = have2[h] ? ib2[h] : 0u;
+            }
+            if (__ballot(have2[0] || have2[1]) == 0) continue;       // a small tree fills the first blocks only
+            // the reference's sum, coordinate by coordinate (0.0 + x*x == x*x, then + y*y, ...): eight nodes' sums side by side
+            double d8[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) sk2[h] = *reinterpret_cast<const uint32_t*>(skip + il2[h]);
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                const ldouble4 ck = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il);
+                ldouble4 ck[2];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const double df = ck[t] - q[k];
-                    const double sq = df * df;
-                    d4[t] = k == 0 ? sq : d4[t] + sq;
+                for (int h = 0; h < 2; ++h) ck[h] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il2[h]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double df = ck[h][t] - q[k];
+                        const double sq = df * df;
+                        d8[h][t] = k == 0 ? sq : d8[h][t] + sq;
+                    }
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (have && ib + (uint32_t)t < bmin && ((sk4 >> (8 * t)) & 0xFFu) == 0) scan_push(pd, d4[t], ib + (uint32_t)t);
-        }
-        {
-            const uint32_t lo = wave_min_u32(act ? bmin : 0xFFFFFFFFu);
-            for (uint32_t i = lo; i < n; ++i) {
-                double c[D];
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) c[k] = sh.newn[k][i & (kNRing - 1)];
-                const double d = dist2<D>(c, q, DIM);
-                if (act && i >= bmin) scan_push(pd, d, i);  // (+inf for skipped duplicates: never pushed as a minimum)
+                for (int t = 0; t < 4; ++t)
+                    if (have2[h] && ib2[h] + (uint32_t)t < bmin && ((sk2[h] >> (8 * t)) & 0xFFu) == 0) scan_push(pd, d8[h][t], ib2[h] + (uint32_t)t);
             }
         }
+        OXHIP_PHASE(0);   // combine + the winning lane's candidates
+        // this lane's query as the screens see it: Q = -2 fl32(q - c0), |b|^2
+        float Qf[D];
+        double bb = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float bk = (float)(q[k] - c0[k]);
+            Qf[k] = -2.0f * bk;
+            bb += (double)bk * (double)bk;
+        }
+        {
+            // A ring node can become this lane's nearest node, or tie with it, only if its d2 is at most T = g0 (1 + 2^-19)
+            // (g0 = the best so far); its screen value then obeys s' <= T - |b|^2 + E.  Everything else is skipped after
+            // D fused multiply-adds; the few that pass get the reference's binary64 distance.
+            const float thr = (mg.usable && pd.b1 < 1e300) ? f32_up(pd.b1 * (1.0 + 0x1p-19) - bb + mg.e2) : __builtin_inff();
+            const uint32_t lo = wave_min_u32(act ? bmin : 0xFFFFFFFFu);
+            // (eight ring nodes per trip: their LDS reads -- wave-uniform addresses -- are issued together)
+            for (uint32_t i0 = lo; i0 < n; i0 += 8) {
+                uint32_t lookm = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const uint32_t i = i0 + (uint32_t)t;
+                    const float* nf = sh.newn32[i & (kNRing - 1)];   // (slots past n hold stale nodes: masked below)
+                    float sp = nf[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sp = __builtin_fmaf(nf[k], Qf[k], sp);
+                    lookm |= (act && i >= bmin && i < n && !(sp > thr)) ? (1u << t) : 0u;   // (NaN: look)
+                }
+                if (__ballot(lookm != 0) != 0) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (__ballot((lookm >> t) & 1u) != 0) {
+                            const uint32_t i = i0 + (uint32_t)t;
+                            double c[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) c[k] = sh.newn[k][i & (kNRing - 1)];
+                            const double d = dist2<D>(c, q, DIM);
+                            if ((lookm >> t) & 1u) scan_push(pd, d, i);  // ascending i: ties keep the lower index (+inf for skipped duplicates)
+                        }
+                    }
+                }
+            }
+        }
+        OXHIP_PHASE(1);   // ring fold
         const double g = pd.b1;
         const uint32_t hb = hi32(g) + 1;
         const uint32_t nearest = pd.slot;
         // accept iff every node this lane did not look at -- the other scanner lanes' -- is provably farther:
         //   d_other^2 >= K2 + |b|^2 - E   >   g
-        bool clear;
-        {
-            double bb = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) { const double bk = (double)(float)(q[k] - c0[k]); bb += bk * bk; }
-            clear = act && mg.usable && nearest != kNoNode && (g < (double)K2 + bb - mg.e2);   // (NaN on either side: false)
-        }
+        const bool clear = act && mg.usable && nearest != kNoNode && (g < (double)K2 + bb - mg.e2);   // (NaN on either side: false)
         // ambiguous iff that proof fails, or a second candidate is within a rounding of the binary64 minimum
         const bool amb = act && (!clear || pd.h2 <= hb);
         double q_near[D], qn[D], mid[D];
@@ -697,28 +771,56 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         }
         steer<DIM>(p, false, g, q_near, q, qn);
         const bool dup = g == 0.0;
+        OXHIP_PHASE(2);   // nearest node's coordinates + steer
         // check_motion (rrt.rs:90-116): the midpoint filter names the spheres the segment can touch at all ...
         bool bad = false;
         if (nobs > 0) {
             lerp<DIM>(q_near, qn, 0.5, mid, DIM);
-            // (eight spheres per trip: their LDS reads -- wave-uniform addresses, broadcast -- are issued together, so the
-            // loop runs at the arithmetic's pace instead of one LDS round trip per sphere; slots beyond ns64 hold -1 thresholds)
-            constexpr int U = DIM <= 3 ? 8 : 4;   // spheres per trip (registers: U x (DIM + 1) doubles)
-            uint32_t maybe_lo = 0, maybe_hi = 0;
-            for (uint32_t o0 = 0; o0 < ns64; o0 += U) {
-                double c[U][D], f[U];
+            // (binary32 first: a sphere whose screen value proves d2(centre, mid) > filter threshold is cleared after D fused
+            // multiply-adds, an add and a compare; only the rest get the binary64 test.  Eight spheres per trip: their LDS
+            // reads -- wave-uniform addresses, broadcast -- are issued together)
+            float Qm[D], mm = 0.0f;
+            {
+                double mmd = 0.0;
 #pragma unroll
-                for (int t = 0; t < U; ++t) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) c[t][k] = sh.obs[k][o0 + t];
-                    f[t] = sh.obs[D + 1][o0 + t];
+                for (int k = 0; k < D; ++k) {
+                    const float mk = (float)(mid[k] - c0[k]);
+                    Qm[k] = -2.0f * mk;
+                    mmd += (double)mk * (double)mk;
                 }
+                mm = (float)(mmd * (1.0 - 0x1p-22));   // rounded down: errs towards "maybe"
+            }
+            uint32_t maybe_lo = 0, maybe_hi = 0;
+            for (uint32_t o0 = 0; o0 < ns64; o0 += 8) {
                 uint32_t bits = 0;
 #pragma unroll
-                for (int t = 0; t < U; ++t) bits |= sphere_maybe_hit<DIM>(c[t], f[t], mid) ? (1u << t) : 0u;
+                for (int t = 0; t < 8; ++t) {
+                    const float* of = sh.obs32[o0 + t];
+                    float sp = of[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sp = __builtin_fmaf(of[k], Qm[k], sp);
+                    bits |= !(sp + mm > sh.obs32_thr[o0 + t]) ? (1u << t) : 0u;   // (NaN / inf threshold: maybe; -1: no sphere)
+                }
                 if (o0 < 32) maybe_lo |= bits << o0; else maybe_hi |= bits << (o0 - 32);
             }
+            // the binary64 filter for the spheres the pre-filter left (per lane: usually none or one)
+            {
+                uint64_t rem = ((uint64_t)maybe_hi << 32) | maybe_lo;
+                uint64_t keep = 0;
+                while (__ballot(rem != 0) != 0) {
+                    const bool has = rem != 0;
+                    const uint32_t o = has ? (uint32_t)(__ffsll((unsigned long long)rem) - 1) : 0u;
+                    double c[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) c[k] = sh.obs[k][o];
+                    if (has && sphere_maybe_hit<DIM>(c, sh.obs[D + 1][o], mid)) keep |= 1ull << o;
+                    rem &= rem - 1;
+                }
+                maybe_lo = (uint32_t)keep;
+                maybe_hi = (uint32_t)(keep >> 32);
+            }
             const uint64_t maybe = ((uint64_t)maybe_hi << 32) | maybe_lo;
+            OXHIP_PHASE(3);   // sphere filter
             const bool need = act && !amb && (maybe != 0 || extras);
             if (__ballot(need) != 0) {
                 // ... and every lane steps through its own motion against just those (is_valid is pure: testing all states
@@ -753,8 +855,20 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 }
             }
         }
+        OXHIP_PHASE(4);   // motion check
         const bool ok = act && !bad;
         const bool ins = !p.freeze;
+        // this lane's new node as the scanners (and the binary32 screens) will hold it
+        float nf_a[D], nf_cc;
+        {
+            double sq = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                nf_a[k] = (float)(qn[k] - c0[k]);
+                sq += (double)nf_a[k] * (double)nf_a[k];
+            }
+            nf_cc = (float)sq;
+        }
 
         // ---- the prefix this round may commit
         uint32_t cut = m;
@@ -777,21 +891,54 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
             // a node accepted earlier in the round that is (nearly) as close to a later query as that query's nearest
             // node changes that query's result: the prefix ends before the first such query
+            // (binary32 first, as in the ring fold: the new node of lane i matters to lane j only if d2 <= g_j (1 + 2^-19))
+            // The round's would-be new nodes are staged in the ring slots they will occupy (beyond `committed`: nobody reads
+            // them yet, and the slots belong to nodes too old to matter); the t-th of them concerns the lanes behind its own,
+            // i.e. the lanes with more than t inserting lanes below them.
             const uint64_t newm = __ballot(ok && !dup);
-            for (uint64_t rest = newm; rest != 0; rest &= rest - 1) {
-                const int i = __ffsll((unsigned long long)rest) - 1;
-                if ((uint32_t)i + 1u >= cut) break;
-                double ca[D];
+            const uint32_t rank = (uint32_t)__popcll(newm & below_mask(lane));
+            const float thr_c = (mg.usable && g < 1e300) ? f32_up(g * (1.0 + 0x1p-19) - bb + mg.e2) : __builtin_inff();
+            if (ok && !dup) {
+                const uint32_t sl = (n + rank) & (kNRing - 1);
 #pragma unroll
-                for (int k = 0; k < D; ++k) ca[k] = readlane_f64(qn[k], i);
-                const uint64_t cm = __ballot(act && lane > (uint32_t)i && hi32(dist2<D>(ca, q, DIM)) <= hb);
-                if (cm != 0) {
-                    const uint32_t c = (uint32_t)(__ffsll((unsigned long long)cm) - 1);
-                    if (c < cut) { cut = c; stop_after = -1; if (STAMP) ++n_cut_conflict; }
+                for (int k = 0; k < D; ++k) { sh.newn32[sl][k] = nf_a[k]; sh.newn[k][sl] = qn[k]; }
+                sh.newn32[sl][D] = nf_cc;
+            }
+            const uint32_t n_new = (uint32_t)__popcll(newm);
+            for (uint32_t t0 = 0; t0 < n_new; t0 += 8) {
+                // lanes in front of the first inserting lane of this trip are out of reach; so is everything behind the cut
+                uint32_t lookm = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float* nf = sh.newn32[(n + t0 + (uint32_t)t) & (kNRing - 1)];
+                    float sp = nf[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sp = __builtin_fmaf(nf[k], Qf[k], sp);
+                    lookm |= (act && rank > t0 + (uint32_t)t && t0 + (uint32_t)t < n_new && lane < cut && !(sp > thr_c)) ? (1u << t) : 0u;
                 }
+                if (__ballot(lookm != 0) != 0) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (__ballot((lookm >> t) & 1u) != 0) {
+                            const uint32_t sl = (n + t0 + (uint32_t)t) & (kNRing - 1);
+                            double ca[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) ca[k] = sh.newn[k][sl];
+                            const uint64_t cm = __ballot(((lookm >> t) & 1u) != 0 && hi32(dist2<D>(ca, q, DIM)) <= hb);
+                            if (cm != 0) {
+                                const uint32_t c = (uint32_t)(__ffsll((unsigned long long)cm) - 1);
+                                if (c < cut) { cut = c; stop_after = -1; if (STAMP) ++n_cut_conflict; }
+                            }
+                        }
+                    }
+                }
+                // the nodes of the next trip come from lanes at or behind this one's: nothing left to learn once they pass the cut
+                const uint64_t behind = newm & ~first_n_mask(cut);
+                if (t0 + 8 >= n_new - (uint32_t)__popcll(behind)) break;
             }
         }
 
+        OXHIP_PHASE(5);   // prefix: cap, goal, conflicts
         // ---- commit lanes [0, cut) in query order
         if (cut > 0) {
             const uint64_t cutm = first_n_mask(cut);
@@ -805,8 +952,10 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
                         sh.newn[k][idx & (kNRing - 1)] = dup ? __builtin_inf() : qn[k];
+                        sh.newn32[idx & (kNRing - 1)][k] = dup ? 0.0f : nf_a[k];
                         tree[(size_t)k * cap + idx] = qn[k];
                     }
+                    sh.newn32[idx & (kNRing - 1)][D] = dup ? __builtin_inff() : nf_cc;
                     parent[idx] = (int32_t)nearest;
                     skip[idx] = dup ? 1 : 0;
                 }
@@ -835,6 +984,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             jr += cut;
             if (lane == 0) lds_post(&sh.resolved, jr);   // the sampler may hand the slots out again
         }
+        OXHIP_PHASE(6);   // commit
         if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
         if (stop_after >= 0) { stop = stop_after; break; }
         if (cut == m || ambm == 0 || (uint32_t)(__ffsll((unsigned long long)ambm) - 1) != cut) continue;
@@ -955,11 +1105,16 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 if (!p.freeze) {
                     const uint32_t i = n;
                     if (lane == 0) {
+                        double sq1 = 0.0;
 #pragma unroll
                         for (int k = 0; k < D; ++k) {
+                            const float f1 = (float)(qn1[k] - c0[k]);
+                            sq1 += (double)f1 * (double)f1;
                             sh.newn[k][i & (kNRing - 1)] = dup1 ? __builtin_inf() : qn1[k];
+                            sh.newn32[i & (kNRing - 1)][k] = dup1 ? 0.0f : f1;
                             tree[(size_t)k * cap + i] = qn1[k];
                         }
+                        sh.newn32[i & (kNRing - 1)][D] = dup1 ? __builtin_inff() : (float)sq1;
                         parent[i] = (int32_t)nearest1;
                         skip[i] = dup1 ? 1 : 0;
                     }
@@ -985,6 +1140,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         p.state[prob] = st;
         if (STAMP && p.dbg && prob == 0) {
             p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_exact; p.dbg[15] = n_tie; p.dbg[11] = n_memo;
+            for (int i = 0; i < 8; ++i) p.dbg[32 + i] = t_ph[i];
             p.dbg[13] = (uint64_t)clock64() - t_begin; p.dbg[14] = (uint64_t)__builtin_amdgcn_s_memrealtime() - rt_begin;
         }
     }

@@ -21,6 +21,8 @@ print("  resolver: wait %.0f  work %.0f cycles per iteration (%.0f per round); e
       % (int(s[1]) / itg, int(s[2]) / itg, int(s[2]) / max(1, int(s[5])), int(s[3]) / itg, int(s[3]) / max(1, int(s[4])), int(s[14]) / 1e5, int(s[13]) / max(1, int(s[14])) / 10.0))
 print("  scanner waves: wait", " ".join("%6.0f" % (int(v) / itg) for v in s[16:24]))
 print("                 work", " ".join("%6.0f" % (int(v) / itg) for v in s[24:32]))
+PH = ("combine+candidates", "ring fold", "coords+steer", "sphere filter", "motion check", "prefix (cap, goal, conflicts)", "commit")
+print("  resolver phases, cycles per round:", ", ".join("%s %.0f" % (nm, int(s[32 + i]) / max(1, int(s[5]))) for i, nm in enumerate(PH)))
 gpu.solve(iters, freeze=True)
 s2 = gpu.stamps()
 it = int(s2[7]) - int(s[7])
@@ -32,3 +34,4 @@ print("               work   ", " ".join("%6.0f" % (int(v) / it) for v in s2[24:
 print("resolver lifetime: %d cycles in %.3f ms (100 MHz clock) = %.2f GHz; exact path %.0f cycles per iteration (%.0f per event)"
       % (int(s2[13]), int(s2[14]) / 1e5, int(s2[13]) / max(1, int(s2[14])) / 10.0, int(s2[3]) / it, int(s2[3]) / max(1, int(s2[4]))))
 print("literal-loop (true near-tie) events: %d; whole-tree answers reused: %d" % (int(s2[15]), int(s2[11])))
+print("resolver phases, cycles per round:", ", ".join("%s %.0f" % (nm, int(s2[32 + i]) / max(1, int(s2[5]))) for i, nm in enumerate(PH)))
