@@ -93,6 +93,46 @@ def test_resident32_headline_kernel_keeps_its_shape(resident32_asm):
 
 
 @pytest.fixture(scope="module")
+def lanes_asm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("asm") / "rrt_lanes.s")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "rrt_lanes.hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_lanes_headline_kernel_keeps_its_shape(lanes_asm):
+    """the kernel KERNEL_AUTO runs for BASELINE.json configs[1] (steady measurement), rrt_lanes_kernel<3,24,16,false>: the tree
+    stays in VGPRs (no spill, no scratch), three waves fit a SIMD, and the screen is what DESIGN.md 5.5 prices: per 64-node
+    register row and query pair D = 3 packed fused multiply-adds with the row picked by op_sel (24 rows x 4 pairs x 3 = 288)
+    and one v_min_f32 per query (192), with nothing between them that moves data across lanes or touches memory"""
+    meta = {k: v for k, v in _kernels(lanes_asm).items() if "rrt_lanes_kernel" in k}
+    assert len(meta) >= 12   # R^2..R^6 x row counts x {product, stamped diagnostic}
+    name = [k for k in meta if "ILi3ELi24ELi16ELb0" in k][0]
+    m = meta[name]
+    assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] <= 64, m   # (a demoted tree would need kilobytes of scratch)
+    assert m["max_flat_workgroup_size"] == 640 and m["vgpr_count"] <= 168     # 10 waves per CU -> 3 on two of the SIMDs -> 512 / 3
+    assert m["group_segment_fixed_size"] <= 64 * 1024
+    for k, mm in meta.items():   # R^2 .. R^5 at 10,240 nodes: no spill inside the product kernels' hot loop would show as scratch here
+        if "Lb0" in k and any(t in k for t in ("ILi2ELi24ELi16", "ILi3ELi24ELi16")):
+            assert mm["vgpr_spill_count"] == 0, k
+    body = lanes_asm.split(name + ":")[1].split("s_endpgm")[0]
+    lines = body.split("\n")
+    # the scanners' fused multiply-adds take the query pair from scalar registers (the resolver's own binary32 pre-screens,
+    # which the compiler may also pack, do not)
+    scan = [i for i, l in enumerate(lines) if "v_pk_fma_f32" in l and ", s[" in l]
+    first, last = scan[0], scan[-1]
+    screen = "\n".join(lines[first:last + 1])
+    assert len(scan) == 288 and screen.count("v_min_f32") >= 180
+    assert "op_sel:[1,0" in screen                                   # odd rows come out of the upper half of a register pair
+    for bad in ("v_pk_add_f32", "v_pk_mul_f32", "v_and_or_b32", "v_med3_u32", "scratch_", "global_load", "ds_bpermute", "v_readlane"):
+        assert bad not in screen, bad
+    assert "v_min_f32_dpp" in body and "s_setprio" in body
+    # the resolver's exact work is unfused binary64 (the reference never fuses): sub / mul / add, no v_fma_f64 outside sqrt / division
+    assert body.count("v_mul_f64") > 100 and body.count("v_add_f64") > 100
+
+
+@pytest.fixture(scope="module")
 def prm_asm(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("asm") / "prm_kernels.s")
     subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",

@@ -48,13 +48,15 @@ def case_rv(planner):
     gr = float(rng.choice([0.02, 0.1])) * w
     seed, pid0 = int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 2 ** 20))
     nprob = int(rng.choice([1, 3, 9]))
-    max_nodes = int(rng.choice([50, 400, 2500]))
-    iters = int(rng.choice([60, 500, 3000]))
+    max_nodes = int(rng.choice([50, 400, 2500, 2500, 9000]))
+    iters = int(rng.choice([60, 500, 3000, 3000, 12000]))
     stop = bool(rng.random() < 0.5)
     radius = float(rng.choice([0.0, 0.05, 0.15, 0.5])) * w
     kernels = [capi.KERNEL_STREAM]
     if planner == capi.PLANNER_RRT and dim in (2, 3):
         kernels += [capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32]
+    if planner == capi.PLANNER_RRT and 2 <= dim <= 6:
+        kernels += [capi.KERNEL_LANES, capi.KERNEL_LANES, capi.KERNEL_AUTO]   # the default path: weighted up
     kernel = int(rng.choice(kernels))
     desc = dict(planner=planner, kernel=kernel, dim=dim, lo=lo, hi=hi, md=md, gb=gb, frac=frac, ns=len(sr), nb=len(blo),
                 seed=seed, pid0=pid0, nprob=nprob, max_nodes=max_nodes, iters=iters, stop=stop, radius=radius)
@@ -81,6 +83,9 @@ def case_rv(planner):
         g.solve(iters - a)
     else:
         g.solve(iters)
+    frozen = int(rng.choice([0, 0, 64, 700, 3000])) if planner == capi.PLANNER_RRT else 0   # then some iterations with inserts off
+    if frozen:
+        g.solve(frozen, freeze=True)
     c = g.counts()
     for p in range(nprob):
         if planner == capi.PLANNER_RRT:
@@ -95,6 +100,8 @@ def case_rv(planner):
             o.set_boxes(blo, bhi)
         o.setup(start, goal, gr)
         o.solve(iters)
+        if frozen:
+            o.solve(frozen, freeze=True)
         ok = int(c["checksum"][p]) == o.checksum and int(c["iterations"][p]) == o.iterations
         if planner == capi.PLANNER_RRT_CONNECT:
             gc = g.goal_counts()
