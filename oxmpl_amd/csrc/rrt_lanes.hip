@@ -721,7 +721,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             // A ring node can become this lane's nearest node, or tie with it, only if its d2 is at most T = g0 (1 + 2^-19)
             // (g0 = the best so far); its screen value then obeys s' <= T - |b|^2 + E.  Everything else is skipped after
             // D fused multiply-adds; the few that pass get the reference's binary64 distance.
-            const float thr = (mg.usable && pd.b1 < 1e300) ? f32_up(pd.b1 * (1.0 + 0x1p-19) - bb + mg.e2) : __builtin_inff();
+            float thr = (mg.usable && pd.b1 < 1e300) ? f32_up(pd.b1 * (1.0 + 0x1p-19) - bb + mg.e2) : __builtin_inff();
             const uint32_t lo = wave_min_u32(act ? bmin : 0xFFFFFFFFu);
             // (eight ring nodes per trip: their LDS reads -- wave-uniform addresses -- are issued together)
             for (uint32_t i0 = lo; i0 < n; i0 += 8) {
@@ -747,16 +747,31 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                             if ((lookm >> t) & 1u) scan_push(pd, d, i);  // ascending i: ties keep the lower index (+inf for skipped duplicates)
                         }
                     }
+                    // a lane whose best just improved looks at fewer of the nodes to come (a lane that had no candidate at all
+                    // -- its nearest node is itself young -- started with thr = +inf)
+                    if (mg.usable && pd.b1 < 1e300) thr = f32_up(pd.b1 * (1.0 + 0x1p-19) - bb + mg.e2);
                 }
             }
         }
         OXHIP_PHASE(1);   // ring fold
+        // accept iff every node this lane did not look at -- the other scanner lanes' -- is provably farther:
+        //   d_other^2 >= K2 + |b|^2 - E   >   g
+        bool clear = act && mg.usable && pd.slot != kNoNode && (pd.b1 < (double)K2 + bb - mg.e2);   // (NaN on either side: false)
+        // The whole-tree path's last answer (below) stands while the tree has not grown: a lane with that very query -- the
+        // goal centre, drawn again and again -- takes it here instead of ending the round's prefix every time.
+        {
+            bool same_q = act && memo_n == n && !(clear && pd.h2 > hi32(pd.b1) + 1);
+#pragma unroll
+            for (int k = 0; k < D; ++k) same_q = same_q && __double_as_longlong(q[k]) == __double_as_longlong(memo_q[k]);
+            if (same_q) {
+                pd.b1 = memo_g; pd.slot = memo_idx; pd.h2 = 0xFFFFFFFFu;   // (stored only when the minimum was unique)
+                clear = true;
+            }
+            if (STAMP) n_memo += (uint64_t)__popcll(__ballot(same_q));
+        }
         const double g = pd.b1;
         const uint32_t hb = hi32(g) + 1;
         const uint32_t nearest = pd.slot;
-        // accept iff every node this lane did not look at -- the other scanner lanes' -- is provably farther:
-        //   d_other^2 >= K2 + |b|^2 - E   >   g
-        const bool clear = act && mg.usable && nearest != kNoNode && (g < (double)K2 + bb - mg.e2);   // (NaN on either side: false)
         // ambiguous iff that proof fails, or a second candidate is within a rounding of the binary64 minimum
         const bool amb = act && (!clear || pd.h2 <= hb);
         double q_near[D], qn[D], mid[D];

@@ -311,6 +311,26 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+def test_long_motion_checks_are_not_a_stalled_pipeline(kernel):
+    """A tiny longest-valid-segment fraction makes every motion check 300,000 interpolated states against 48 boxes
+    (boxes are stepped, never filtered): the resident kernels' resolver then works for longer than the watchdog of the
+    waves waiting on it, which must read its heartbeat instead of reporting a stalled hand-off."""
+    rng = np.random.default_rng(5)
+    lo = np.column_stack([rng.uniform(0.5, 9.0, 48), rng.uniform(6.0, 9.5, 48)])
+    sc = dict(dim=2, bounds=[(0.0, 10.0), (0.0, 10.0)], max_distance=0.5, goal_bias=0.05,
+              lvs_fraction=0.5 / (3.0e5 * 0.1 * math.sqrt(200.0)), start=[1.0, 1.0], goal_centre=[9.0, 1.0], goal_radius=0.3,
+              spheres=None, boxes=(lo, lo + 0.2))
+    P, iters = 3, 24
+    gpu = _gpu_for(sc, P, 64, False, 3, 0, kernel)
+    gpu.solve(iters)
+    planners = [_oracle_for(sc, 3, p, 64, False) for p in range(P)]
+    orc.solve_many(planners, iters, threads=3)
+    for p in range(P):
+        _assert_same_problem(gpu, p, planners[p])
+    gpu.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
 def test_rrt_termination_resume_and_freeze(kernel):
     sc = scenarios.config2()
     # node cap: stops at max_nodes without drawing further
