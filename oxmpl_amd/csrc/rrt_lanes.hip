@@ -45,13 +45,19 @@ typedef float lf32x2 __attribute__((ext_vector_type(2)));
 constexpr int kLanesThreads = kScanThreads + 128;   // + the resolver wave + the sampler wave
 constexpr int kQRing = 128;                         // queries in flight (power of two)
 constexpr int kNRing = 256;                         // committed nodes kept in LDS (power of two, >= kQRing + 64)
-template <int DIM> struct LanesPass { static constexpr int Q = DIM >= 6 ? 4 : 8; };   // queries one scanner pass covers (register budget)
+#ifndef OXHIP_LANES_PASS3
+#define OXHIP_LANES_PASS3 8
+#endif
+template <int DIM> struct LanesPass { static constexpr int Q = DIM >= 6 ? 4 : (DIM <= 3 ? OXHIP_LANES_PASS3 : 8); };   // queries one scanner pass covers (register budget)
 #ifndef OXHIP_DEPTH_GROW
 #define OXHIP_DEPTH_GROW 96
 #endif
 constexpr uint32_t kDepthGrow = OXHIP_DEPTH_GROW;                 // queries sampled ahead of the resolver while inserts are on
 #ifndef OXHIP_LANES_PRIO
 #define OXHIP_LANES_PRIO 16
+#endif
+#ifndef OXHIP_LANES_QSGPR
+#define OXHIP_LANES_QSGPR 0   // 1: the pass's queries in scalar registers (24 v_readfirstlane per pass); 0: in vector register pairs
 #endif
 
 struct alignas(16) LanePub {   // one wave's screen result for one query (one 16-byte LDS record)
@@ -104,7 +110,7 @@ struct LanesShared {
     uint32_t rng_buf[16][64];
     double q[DIM][kQRing];               // the queries, coordinate-major: resolver lane j reads q[k][slot_j] conflict-free
     uint64_t pos_after[kQRing];          // stream position after each query's draws
-    float qf[kQRing][DIM <= 4 ? 4 : 8];  // Q = -2 fl32(q - c0): what the scanners screen with (one or two 16-byte uniform reads per query)
+    float qf[DIM][kQRing];               // Q = -2 fl32(q - c0), coordinate-major: a scanner reads a query PAIR's coordinate with one 8-byte uniform read
     LanePub pub[kScanWaves][kQRing];     // wave-major: resolver lane j reads pub[w][slot_j] conflict-free
     double newn[DIM][kNRing];            // the last kNRing committed nodes, node i at i & (kNRing - 1); +inf for skipped duplicates
     double obs[DIM + 2][64];             // first 64 spheres: centre, validity threshold, filter threshold
@@ -224,7 +230,7 @@ __device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p,
 #pragma unroll
         for (int k = 0; k < DIM; ++k) {
             sh.q[k][slot] = q[k];
-            sh.qf[slot][k] = -2.0f * (float)(q[k] - c0[k]);
+            sh.qf[k][slot] = -2.0f * (float)(q[k] - c0[k]);
         }
         sh.pos_after[slot] = pos0 + off + cnt;
     }
@@ -372,12 +378,22 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
             n_local = nc;
             // the pass's queries Q = -2 fl32(q - c0), two per packed register
+            // (a pass starts on a multiple of its width, so a pair's two slots are adjacent and 8-byte aligned; in the last, short
+            // pass the slots beyond the budget hold older queries: screened and never published)
             lf32x2 q[kPassQ / 2][D];
 #pragma unroll
-            for (int b = 0; b < kPassQ; ++b) {
-                const uint32_t slot = (j + ((uint32_t)b < nb ? (uint32_t)b : 0u)) & (kQRing - 1);
+            for (int bp = 0; bp < kPassQ / 2; ++bp) {
+                const uint32_t slot = (j + 2u * (uint32_t)bp) & (kQRing - 1);
 #pragma unroll
-                for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = lbits_f32(uni(lf32_bits(sh.qf[slot][k])));   // wave-uniform: scalar registers
+                for (int k = 0; k < D; ++k) {
+                    const lf32x2 v = *reinterpret_cast<const lf32x2*>(&sh.qf[k][slot]);
+#if OXHIP_LANES_QSGPR
+                    q[bp][k][0] = lbits_f32(uni(lf32_bits(v[0])));   // wave-uniform: scalar registers
+                    q[bp][k][1] = lbits_f32(uni(lf32_bits(v[1])));
+#else
+                    q[bp][k] = v;   // every lane holds the same pair: a vector register pair, no v_readfirstlane
+#endif
+                }
             }
             uint32_t nrows = Lay::rows_in_use(wave, nc);
             if (nrows > my_rows) nrows = my_rows;
@@ -435,18 +451,16 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) k2w[b0 + t] = t4[t];
             }
+            if (lane == 0) {   // (records of the slots beyond a short last pass are never read)
 #pragma unroll
-            for (int b = 0; b < kPassQ; ++b) {
-                if ((uint32_t)b < nb) {
+                for (int b = 0; b < kPassQ; ++b) {
                     const uint32_t slot = (j + (uint32_t)b) & (kQRing - 1);
-                    if (lane == 0) {
-                        LanePub out;
-                        out.k1 = lf32_bits(k1w[b]);
-                        out.k2 = lf32_bits(k2w[b]);
-                        out.th = wave * 64u + (uint32_t)wl[b];
-                        out.nc = nc;
-                        sh.pub[wave][slot] = out;
-                    }
+                    LanePub out;
+                    out.k1 = lf32_bits(k1w[b]);
+                    out.k2 = lf32_bits(k2w[b]);
+                    out.th = wave * 64u + (uint32_t)wl[b];
+                    out.nc = nc;
+                    sh.pub[wave][slot] = out;
                 }
             }
             if (lane == 0) lds_post(&sh.wave_done[wave], need);   // after the records (LDS is in order within a wave)
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                         for (int k = 0; k < D; ++k) {
                             sh.q[k][slot] = qn[k];
-                            sh.qf[slot][k] = -2.0f * (float)(qn[k] - c0[k]);
+                            sh.qf[k][slot] = -2.0f * (float)(qn[k] - c0[k]);
                         }
                         sh.pos_after[slot] = rng.pos;
                     }
