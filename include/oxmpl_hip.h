@@ -71,8 +71,8 @@ typedef enum oxhip_space_kind {
 } oxhip_space_kind;
 
 typedef enum oxhip_kernel_kind {
-    OXHIP_KERNEL_AUTO = 0,      /* a register-resident kernel when the tree fits the register file (per launch: OXHIP_KERNEL_LANES,
-                                   or OXHIP_KERNEL_RESIDENT_F32 while an R^2 / R^3 tree grows), else streaming */
+    OXHIP_KERNEL_AUTO = 0,      /* OXHIP_KERNEL_LANES when the tree fits its register rows (R^2 .. R^6), else the older resident
+                                   kernels (R^2 / R^3), else streaming */
     OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
     OXHIP_KERNEL_RESIDENT = 2,  /* tree held in the workgroup's vector registers, every node scanned */
     OXHIP_KERNEL_PRUNED = 3,    /* experiment, only in builds made with WITH_PRUNED=1 (else OXHIP_ERR_BAD_ARG): resident + box-pruned scan */

@@ -50,11 +50,14 @@ constexpr int kNRing = 256;                         // committed nodes kept in L
 #endif
 template <int DIM> struct LanesPass { static constexpr int Q = DIM >= 6 ? 4 : (DIM <= 3 ? OXHIP_LANES_PASS3 : 8); };   // queries one scanner pass covers (register budget)
 #ifndef OXHIP_DEPTH_GROW
-#define OXHIP_DEPTH_GROW 96
+#define OXHIP_DEPTH_GROW 64
 #endif
 constexpr uint32_t kDepthGrow = OXHIP_DEPTH_GROW;                 // queries sampled ahead of the resolver while inserts are on
 #ifndef OXHIP_LANES_PRIO
 #define OXHIP_LANES_PRIO 16
+#endif
+#ifndef OXHIP_WANT_DIV_GROW
+#define OXHIP_WANT_DIV_GROW 8   // while inserts are on the resolver starts a round when 1/this of the window is published
 #endif
 #ifndef OXHIP_LANES_QSGPR
 #define OXHIP_LANES_QSGPR 0   // 1: the pass's queries in scalar registers (24 v_readfirstlane per pass); 0: in vector register pairs
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     uint32_t n = st.n_nodes;
     uint32_t jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
-    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = STAMP ? (uint64_t)clock64() : 0;
+    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, n_fold_trips = 0, n_fold_exact = 0, n_conf_trips = 0, n_conf_exact = 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = STAMP ? (uint64_t)clock64() : 0;
     const uint64_t t_begin = t_mark, rt_begin = STAMP ? (uint64_t)__builtin_amdgcn_s_memrealtime() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 // of what has been sampled (the sampler refills by its own rule and may be waiting for this wave)
                 const uint32_t sampled_now = uni(lds_peek(&sh.sampled));
                 const uint32_t coming = (sampled_now >= budget ? budget : (sampled_now & ~(uint32_t)(kPassQ - 1))) - jr;
-                uint32_t want = depth / 2;
+                uint32_t want = p.freeze ? depth / 2 : depth / OXHIP_WANT_DIV_GROW;
                 if (want > coming) want = coming;
                 const uint32_t d = lane < (uint32_t)kScanWaves ? lds_peek(&sh.wave_done[lane & (kScanWaves - 1)]) : 0xFFFFFFFFu;
                 const uint32_t done_all = wave_min_u32(d);
@@ -749,10 +752,12 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                     for (int k = 0; k < D; ++k) sp = __builtin_fmaf(nf[k], Qf[k], sp);
                     lookm |= (act && i >= bmin && i < n && !(sp > thr)) ? (1u << t) : 0u;   // (NaN: look)
                 }
+                if (STAMP) ++n_fold_trips;
                 if (__ballot(lookm != 0) != 0) {
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         if (__ballot((lookm >> t) & 1u) != 0) {
+                            if (STAMP) ++n_fold_exact;
                             const uint32_t i = i0 + (uint32_t)t;
                             double c[D];
 #pragma unroll
@@ -945,10 +950,12 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                     for (int k = 0; k < D; ++k) sp = __builtin_fmaf(nf[k], Qf[k], sp);
                     lookm |= (act && rank > t0 + (uint32_t)t && t0 + (uint32_t)t < n_new && lane < cut && !(sp > thr_c)) ? (1u << t) : 0u;
                 }
+                if (STAMP) ++n_conf_trips;
                 if (__ballot(lookm != 0) != 0) {
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         if (__ballot((lookm >> t) & 1u) != 0) {
+                            if (STAMP) ++n_conf_exact;
                             const uint32_t sl = (n + t0 + (uint32_t)t) & (kNRing - 1);
                             double ca[D];
 #pragma unroll
@@ -1170,6 +1177,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         if (STAMP && p.dbg && prob == 0) {
             p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_exact; p.dbg[15] = n_tie; p.dbg[11] = n_memo;
             for (int i = 0; i < 8; ++i) p.dbg[32 + i] = t_ph[i];
+            p.dbg[40] = n_fold_trips; p.dbg[41] = n_fold_exact; p.dbg[42] = n_conf_trips; p.dbg[43] = n_conf_exact;
             p.dbg[13] = (uint64_t)clock64() - t_begin; p.dbg[14] = (uint64_t)__builtin_amdgcn_s_memrealtime() - rt_begin;
         }
     }

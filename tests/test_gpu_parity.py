@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 from oxmpl_amd import capi, scenarios  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
 
-# KERNEL_AUTO switches kernels between launches (grow: resident_f32, frozen: lanes); KERNEL_PRUNED is an experiment, not in the product build
+# KERNEL_AUTO = what a user gets (the lane-per-query kernel where it exists); KERNEL_PRUNED is an experiment, not in the product build
 KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES, capi.KERNEL_AUTO]
 KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_PRUNED: "pruned",
          capi.KERNEL_RESIDENT_F32: "resident_f32", capi.KERNEL_LANES: "lanes", capi.KERNEL_AUTO: "auto"}

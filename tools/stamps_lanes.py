@@ -23,6 +23,8 @@ print("  scanner waves: wait", " ".join("%6.0f" % (int(v) / itg) for v in s[16:2
 print("                 work", " ".join("%6.0f" % (int(v) / itg) for v in s[24:32]))
 PH = ("combine+candidates", "ring fold", "coords+steer", "sphere filter", "motion check", "prefix (cap, goal, conflicts)", "commit")
 print("  resolver phases, cycles per round:", ", ".join("%s %.0f" % (nm, int(s[32 + i]) / max(1, int(s[5]))) for i, nm in enumerate(PH)))
+print("  per round: ring-fold trips of eight %.1f, nodes that needed binary64 %.1f; conflict trips %.1f, exact tests %.1f"
+      % tuple(int(s[40 + i]) / max(1, int(s[5])) for i in range(4)))
 gpu.solve(iters, freeze=True)
 s2 = gpu.stamps()
 it = int(s2[7]) - int(s[7])
