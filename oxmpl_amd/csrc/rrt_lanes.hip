@@ -485,7 +485,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st0.draws);
         uint32_t js = 0;
         while (js < budget) {
-            uint32_t jr_seen = 0;
+            uint32_t jr_seen = 0, depth_now = depth;
             bool go = false;
             uint32_t hb_seen = lds_peek(&sh.heartbeat);
             for (uint32_t spins = 0;; ++spins) {
@@ -497,11 +497,18 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                     spins = 0;
                 }
                 jr_seen = uni(lds_peek(&sh.resolved));
-                if (js - jr_seen + 2u * (uint32_t)kPassQ <= depth) { go = true; break; }   // two scanner passes' worth of the window is free: refill it
+                // While a tree is small a round commits few lanes (~sqrt(2n)) and every query in flight has to fold in every node
+                // committed since its scan: the window follows the tree size (n / 8, at least two passes) up to `depth`.
+                depth_now = depth;
+                if (!p.freeze) {
+                    const uint32_t dn = uni(lds_peek(&sh.committed)) / 8u;
+                    depth_now = dn < 2u * (uint32_t)kPassQ ? 2u * (uint32_t)kPassQ : (dn < depth ? dn : depth);
+                }
+                if (js - jr_seen + 2u * (uint32_t)kPassQ <= depth_now || js == jr_seen) { go = true; break; }   // two scanner passes' worth of the window is free: refill it
                 __builtin_amdgcn_s_sleep(2);
             }
             if (!go) break;  // stop requested (or a protocol bug: the resolver's own guard reports it)
-            uint32_t m = jr_seen + depth - js;  // free window slots
+            uint32_t m = jr_seen + depth_now > js ? jr_seen + depth_now - js : (uint32_t)kPassQ;  // free window slots
             if (m > 64u) m = 64u;
             if (m > (uint32_t)kPassQ) m -= (js + m) & (uint32_t)(kPassQ - 1);     // the scanners consume whole passes: end the batch on a pass boundary
             if (m > budget - js) m = budget - js;
