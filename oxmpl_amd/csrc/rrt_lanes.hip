@@ -120,6 +120,7 @@ struct LanesShared {
     float newn32[kNRing][DIM < 4 ? 4 : 8];   // the same nodes as the scanners hold them: a = fl32(x - c0), then cc = fl32(|a|^2) (+inf: skipped)
     float obs32[64][DIM < 4 ? 4 : 8];        // the spheres for the binary32 pre-filter: fl32(centre - c0), then fl32(|.|^2)
     float obs32_thr[64];                     // ... and the filter threshold + error bound, rounded up (-1: no sphere)
+    float fq[64][DIM < 4 ? 4 : 8];           // staging of the pre-filter: lane j's midpoint as -2 fl32(mid - c0), then |.|^2 rounded down
     uint32_t wave_done[kScanWaves];      // queries each scanner wave has published (monotonic)
     uint32_t sampled, resolved, committed, stop_flag;
     uint32_t heartbeat;                  // bumped by the resolver while it works: waiters only give up when it stands still
@@ -584,6 +585,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     const uint64_t t_begin = t_mark, rt_begin = STAMP ? (uint64_t)__builtin_amdgcn_s_memrealtime() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
+    float sph_a[D], sph_cc = 0.0f, sph_thr32 = -1.0f;   // sphere `lane` as the binary32 pre-filter holds it
     LMargins mg;
     {
         // H: the tree as loaded (binary32 roundings, hence the 1 + 2^-23), the bounds and the goal centre, relative to c0
@@ -611,10 +613,14 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             sq += (double)f * (double)f;
         }
         sh.obs32[lane][D] = (float)sq;
+        sph_cc = (float)sq;
         // a sphere is cleared when s' + |m|^2 > thr: thr = (filter threshold + 2 E_f), rounded up (and two ulps more for the sum)
         float thr = (float)((ofilt + ef) * (1.0 + 0x1p-21));
         thr = thr + fabsf(thr) * 0x1p-22f;
-        sh.obs32_thr[lane] = (lane < ns64 && mg.usable && hf < 1e15 && ofilt >= 0.0) ? thr : (lane < ns64 ? __builtin_inff() : -1.0f);
+        sph_thr32 = (lane < ns64 && mg.usable && hf < 1e15 && ofilt >= 0.0) ? thr : (lane < ns64 ? __builtin_inff() : -1.0f);
+        sh.obs32_thr[lane] = sph_thr32;
+#pragma unroll
+        for (int k = 0; k < D; ++k) sph_a[k] = sh.obs32[lane][k];
     }
 
     typedef double ldouble4 __attribute__((ext_vector_type(4)));
@@ -832,6 +838,38 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 mm = (float)(mmd * (1.0 - 0x1p-22));   // rounded down: errs towards "maybe"
             }
             uint32_t maybe_lo = 0, maybe_hi = 0;
+            if (m <= 32u) {
+            // Small rounds (growing trees), transposed: lane s holds sphere s; the round's midpoints are staged in LDS and visited
+            // one by one (wave-uniform reads, four per trip), each costing D fused multiply-adds, an add, a compare (= the
+            // 64-sphere mask of that query) and two v_writelane into the query's own lane -- a round of 10 lanes pays for 10
+            // midpoints, not for 64 spheres.
+            {
+#pragma unroll
+                for (int k = 0; k < D; ++k) sh.fq[lane][k] = Qm[k];
+                sh.fq[lane][D] = mm;
+                for (uint32_t j0 = 0; j0 < m; j0 += 4) {
+                    uint64_t mk[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float* fqj = sh.fq[(j0 + (uint32_t)t) & 63u];
+                        float sp = sph_cc;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) sp = __builtin_fmaf(sph_a[k], fqj[k], sp);
+                        mk[t] = __ballot(!(sp + fqj[D] > sph_thr32));   // (NaN / inf threshold: maybe; -1: no sphere)
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (j0 + (uint32_t)t < m) {
+                            const uint32_t jl = uni(j0 + (uint32_t)t);
+                            // (one scalar operand per VALU instruction on gfx9: the lane select goes through M0)
+                            asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                                : "+v"(maybe_lo), "+v"(maybe_hi) : "s"((uint32_t)mk[t]), "s"(jl), "s"((uint32_t)(mk[t] >> 32)) : "m0");
+                        }
+                    }
+                }
+            }
+            } else {
+            // Full rounds: every lane walks the 64 spheres (eight LDS reads -- wave-uniform, broadcast -- per trip)
             for (uint32_t o0 = 0; o0 < ns64; o0 += 8) {
                 uint32_t bits = 0;
 #pragma unroll
@@ -843,6 +881,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                     bits |= !(sp + mm > sh.obs32_thr[o0 + t]) ? (1u << t) : 0u;   // (NaN / inf threshold: maybe; -1: no sphere)
                 }
                 if (o0 < 32) maybe_lo |= bits << o0; else maybe_hi |= bits << (o0 - 32);
+            }
             }
             // the binary64 filter for the spheres the pre-filter left (per lane: usually none or one)
             {
