@@ -114,7 +114,12 @@ struct LanesShared {
     double q[DIM][kQRing];               // the queries, coordinate-major: resolver lane j reads q[k][slot_j] conflict-free
     uint64_t pos_after[kQRing];          // stream position after each query's draws
     float qf[DIM][kQRing];               // Q = -2 fl32(q - c0), coordinate-major: a scanner reads a query PAIR's coordinate with one 8-byte uniform read
-    LanePub pub[kScanWaves][kQRing];     // wave-major: resolver lane j reads pub[w][slot_j] conflict-free
+    // the scanners' results, field by field and wave-major: resolver lane j reads x[w][slot_j] conflict-free, and a scanner
+    // wave's lane 63 -- where the DPP reduction leaves its result -- stores its values without moving them anywhere first
+    uint32_t pub_k1[kScanWaves][kQRing];   // bits of the smallest screen value s' of the wave
+    uint32_t pub_k2[kScanWaves][kQRing];   // bits of the smallest s' among the wave's other lanes
+    uint32_t pub_th[kScanWaves][kQRing];   // scanner thread (wave * 64 + lane) that holds k1
+    uint32_t pub_nc[kScanWaves][kQRing / 4];   // per pass: tree size the scan covered (the wave's snapshot of `committed`)
     double newn[DIM][kNRing];            // the last kNRing committed nodes, node i at i & (kNRing - 1); +inf for skipped duplicates
     double obs[DIM + 2][64];             // first 64 spheres: centre, validity threshold, filter threshold
     float newn32[kNRing][DIM < 4 ? 4 : 8];   // the same nodes as the scanners hold them: a = fl32(x - c0), then cc = fl32(|a|^2) (+inf: skipped)
@@ -148,11 +153,9 @@ __device__ __forceinline__ void lanes_min4_f32(float (&v)[4]) {
         OXHIP_LMIN4_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
         OXHIP_LMIN4_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
         : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    v[0] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(a), 63));
-    v[1] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(b), 63));
-    v[2] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(c), 63));
-    v[3] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(d), 63));
+    v[0] = a; v[1] = b; v[2] = c; v[3] = d;   // lane 63 holds the four minima
 }
+__device__ __forceinline__ float lane63_f32(float v) { return lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(v), 63)); }
 #undef OXHIP_LMIN4_STEP
 __device__ __forceinline__ void vmin_f32(float& acc, float x) {   // plain v_min_f32 in place: no canonicalising v_max in front,
     asm("v_min_f32 %0, %0, %1" : "+v"(acc) : "v"(x));             // and no renamed register to copy back where branches join
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 }
             }
             // reduce: the wave's smallest s', the lane that holds it, and the smallest among the other lanes
-            float k1w[kPassQ], k2w[kPassQ];
+            float k1v[kPassQ], k2v[kPassQ];   // valid in lane 63
             int wl[kPassQ];
 #pragma unroll
             for (int b0 = 0; b0 < kPassQ; b0 += 4) {
@@ -439,11 +442,11 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 for (int t = 0; t < 4; ++t) t4[t] = b1[b0 + t];
                 lanes_min4_f32(t4);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) k1w[b0 + t] = t4[t];
+                for (int t = 0; t < 4; ++t) k1v[b0 + t] = t4[t];
             }
 #pragma unroll
             for (int b = 0; b < kPassQ; ++b) {
-                const uint64_t eqm = __ballot(lf32_bits(b1[b]) == lf32_bits(k1w[b]));
+                const uint64_t eqm = __ballot(lf32_bits(b1[b]) == lf32_bits(lane63_f32(k1v[b])));
                 wl[b] = eqm ? __ffsll((unsigned long long)eqm) - 1 : 0;
             }
 #pragma unroll
@@ -453,21 +456,19 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 for (int t = 0; t < 4; ++t) t4[t] = (int)lane == wl[b0 + t] ? __builtin_inff() : b1[b0 + t];
                 lanes_min4_f32(t4);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) k2w[b0 + t] = t4[t];
+                for (int t = 0; t < 4; ++t) k2v[b0 + t] = t4[t];
             }
-            if (lane == 0) {   // (records of the slots beyond a short last pass are never read)
+            if (lane == 63) {   // (records of the slots beyond a short last pass are never read)
 #pragma unroll
                 for (int b = 0; b < kPassQ; ++b) {
                     const uint32_t slot = (j + (uint32_t)b) & (kQRing - 1);
-                    LanePub out;
-                    out.k1 = lf32_bits(k1w[b]);
-                    out.k2 = lf32_bits(k2w[b]);
-                    out.th = wave * 64u + (uint32_t)wl[b];
-                    out.nc = nc;
-                    sh.pub[wave][slot] = out;
+                    sh.pub_k1[wave][slot] = lf32_bits(k1v[b]);
+                    sh.pub_k2[wave][slot] = lf32_bits(k2v[b]);
+                    sh.pub_th[wave][slot] = wave * 64u + (uint32_t)wl[b];
                 }
+                sh.pub_nc[wave][((j & (kQRing - 1)) / (uint32_t)kPassQ) & (kQRing / 4 - 1)] = nc;
             }
-            if (lane == 0) lds_post(&sh.wave_done[wave], need);   // after the records (LDS is in order within a wave)
+            if (lane == 63) lds_post(&sh.wave_done[wave], need);   // after the records (LDS is in order within a wave)
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
         }
         if (STAMP && p.dbg && prob == 0 && lane == 0) { p.dbg[16 + wave] = t_wait; p.dbg[24 + wave] = t_work; }
@@ -680,7 +681,12 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         {
             LanePub rec[kScanWaves];
 #pragma unroll
-            for (int w = 0; w < kScanWaves; ++w) rec[w] = sh.pub[w][slot];
+            for (int w = 0; w < kScanWaves; ++w) {
+                rec[w].k1 = sh.pub_k1[w][slot];
+                rec[w].k2 = sh.pub_k2[w][slot];
+                rec[w].th = sh.pub_th[w][slot];
+                rec[w].nc = sh.pub_nc[w][(slot / (uint32_t)kPassQ) & (kQRing / 4 - 1)];
+            }
 #pragma unroll
             for (int w = 0; w < kScanWaves; ++w) {
                 K1 = fminf(K1, lbits_f32(rec[w].k1));   // (never NaN: see the scanner)

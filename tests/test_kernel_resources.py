@@ -118,9 +118,9 @@ def test_lanes_headline_kernel_keeps_its_shape(lanes_asm):
             assert mm["vgpr_spill_count"] == 0, k
     body = lanes_asm.split(name + ":")[1].split("s_endpgm")[0]
     lines = body.split("\n")
-    # the scanners' fused multiply-adds take the query pair from scalar registers (the resolver's own binary32 pre-screens,
-    # which the compiler may also pack, do not)
-    scan = [i for i, l in enumerate(lines) if "v_pk_fma_f32" in l and ", s[" in l]
+    # the scanners' fused multiply-adds broadcast one half of a register pair (op_sel on the first operand: even rows
+    # op_sel_hi:[0,..], odd rows op_sel:[1,..]); packed operations the compiler may form in the resolver do not
+    scan = [i for i, l in enumerate(lines) if "v_pk_fma_f32" in l and ("op_sel_hi:[0," in l or "op_sel:[1," in l)]
     first, last = scan[0], scan[-1]
     screen = "\n".join(lines[first:last + 1])
     assert len(scan) == 288 and screen.count("v_min_f32") >= 180

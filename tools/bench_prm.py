@@ -37,7 +37,20 @@ ph = np.mean(np.array(phases), axis=0)
 pairs = n * (n - 1) // 2
 dim = sc["dim"]
 # the pair search screens in packed binary32: per pair and lane dim subtractions + dim squares / fmas, two pairs per
-# instruction = dim VALU instructions per pair; 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s
+# instruction = dim VALU instructions per pair.  Peak = the MEASURED issue rate of packed binary32 instructions on this
+# chip (tools/valu_mix_bench.hip -> profiles/r2_valu_peak.json: ns per wave64 instruction per SIMD at 4 waves per SIMD,
+# the kernel's occupancy), x 64 lanes x SIMDs -- round 1 assumed 16 lanes x 2.4 GHz = 39.3 T/s
+def packed_f32_peak():
+    try:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r2_valu_peak.json")) as f:
+            d = json.load(f)
+        ns = [d["op_issue"][k]["4w"]["ns"] for k in ("v_pk_fma_f32", "v_pk_add_f32")]
+        return d["cus"] * 4 * 64 / (sum(ns) / len(ns) * 1e-9) / 1e12, "profiles/r2_valu_peak.json: v_pk_fma_f32 / v_pk_add_f32, 4 waves per SIMD"
+    except (OSError, KeyError, ValueError):
+        return 39.3, "assumed: 1024 SIMDs x 16 lanes x 2.4 GHz"
+
+
+PEAK_T, PEAK_SRC = packed_f32_peak()
 instr_pair = dim
 pair_s = ph[1] * 1e-3
 out = {
@@ -48,8 +61,8 @@ out = {
     "milestones_per_s": n / (float(np.mean(walls)) * 1e-3),
     "pairs_per_s": pairs / pair_s,
     "roofline": {"kernel": "prm_pairs_kernel", "bound": "valu", "achieved": pairs * instr_pair / pair_s / 1e12,
-                 "peak": 39.3, "unit": "T lane-instructions/s (packed-f32 screen: dim per pair; 1024 SIMDs x 16 lanes x 2.4 GHz)",
-                 "frac": pairs * instr_pair / pair_s / 1e12 / 39.3,
+                 "peak": PEAK_T, "unit": "T lane-instructions/s (packed-f32 screen: dim per pair)", "peak_source": PEAK_SRC,
+                 "frac": pairs * instr_pair / pair_s / 1e12 / PEAK_T,
                  "hbm_bytes_algorithmic": n * dim * 8},
     "query": {"status": int(st), "path_states": int(len(path)), "kernel_ms": tq[4], "bfs_ms": tq[5]},
 }
