@@ -13,9 +13,11 @@
 //   64 queries).  A lane takes the winning scanner lane's own <= 24 nodes -- four consecutive indices per register-row
 //   block, so 32-byte loads from the binary64 tree -- and the nodes committed after the scans' snapshots (LDS ring), computes
 //   their distances in binary64 exactly as the reference does, and keeps the nearest (lowest index on ties, near-ties
-//   flagged).  It ACCEPTS that node only if every node it did not look at is provably farther:
-//       g  <  K2 + |b|^2 - 2 E,      K2 = smallest s' among all other scanner lanes,   E = u H^2 D (3D + 9)
-//   (error model below).  Otherwise -- ~1e-3 of queries -- the query is resolved alone by the reference's literal loop over
+//   flagged).  It ACCEPTS that node only if every node it did not look at is provably farther (error model below, E = u H^2 D (3D + 9)):
+//       every other scanner lane's smallest s' exceeds K1 + 2.25 E  (K1 = the winning lane's; within the winning wave the scanners
+//                                                                   test this themselves, against K1 + 2.5 E, with one ballot), and
+//       g <= K1 + |b|^2 + E                                        (the best node the lane looked at is the one the screen saw);
+//   then a node it did not look at has d^2 >= s' + |b|^2 - E > K1 + |b|^2 + 1.25 E >= g + E / 4.  Otherwise -- ~1e-3 of queries -- the query is resolved alone by the reference's literal loop over
 //   the binary64 tree.  Everything that enters a result (distance, steer, motion check, tree, checksum) is binary64.
 //
 // Sequential semantics (iteration k sees exactly the tree left by iterations < k, rrt.rs:170-225) are kept by committing,
@@ -65,8 +67,8 @@ constexpr uint32_t kDepthGrow = OXHIP_DEPTH_GROW;                 // queries sam
 
 struct alignas(16) LanePub {   // one wave's screen result for one query (one 16-byte LDS record)
     uint32_t k1;   // bits of the smallest screen value s' of the wave
-    uint32_t k2;   // bits of the smallest s' among the wave's other lanes
-    uint32_t th;   // scanner thread (wave * 64 + lane) that holds k1
+    uint32_t k2;   // (unused)
+    uint32_t th;   // scanner thread (wave * 64 + lane) that holds k1; bit 31: another lane of the wave is within 2.5 E of k1
     uint32_t nc;   // tree size this scan covered (the wave's snapshot of `committed`)
 };
 
@@ -117,8 +119,7 @@ struct LanesShared {
     // the scanners' results, field by field and wave-major: resolver lane j reads x[w][slot_j] conflict-free, and a scanner
     // wave's lane 63 -- where the DPP reduction leaves its result -- stores its values without moving them anywhere first
     uint32_t pub_k1[kScanWaves][kQRing];   // bits of the smallest screen value s' of the wave
-    uint32_t pub_k2[kScanWaves][kQRing];   // bits of the smallest s' among the wave's other lanes
-    uint32_t pub_th[kScanWaves][kQRing];   // scanner thread (wave * 64 + lane) that holds k1
+    uint32_t pub_th[kScanWaves][kQRing];   // scanner thread (wave * 64 + lane) that holds k1; bit 31: another lane of the wave is within 2.5 E of k1
     uint32_t pub_nc[kScanWaves][kQRing / 4];   // per pass: tree size the scan covered (the wave's snapshot of `committed`)
     double newn[DIM][kNRing];            // the last kNRing committed nodes, node i at i & (kNRing - 1); +inf for skipped duplicates
     double obs[DIM + 2][64];             // first 64 spheres: centre, validity threshold, filter threshold
@@ -342,6 +343,20 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         }
         __hip_atomic_fetch_max(&sh.mabs_bits, mab, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();  // the resolver reads mabs_bits after this barrier (the second and last of the launch)
+        // 2.5 E, E as the resolver computes it (same H): a second lane whose smallest s' is within it makes the wave's result "not
+        // proven" (the resolver needs 2.25 E; the sum k1 + 2.5 E rounds by at most half an ulp of 3 D H^2 = E / 6 in R^3, less above)
+        float e4f;
+        {
+            double h = (double)lbits_f32(lds_peek(&sh.mabs_bits)) * (1.0 + 0x1p-23);
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                h = fmax(h, fmax(fabs(p.lo[k] - c0[k]), fabs(p.hi[k] - c0[k])));
+                h = fmax(h, fabs(p.goal_c[(size_t)prob * DIM + k] - c0[k]));
+            }
+            h = unid(h) * 1.001;
+            const bool usable = h < 1e15 && fabs(c0[0]) < 1e300;
+            e4f = usable ? f32_up(2.5 * (0x1p-24 * h * h * (double)(D * (3 * D + 9)) * 1.0001 + 1e-290)) : __builtin_inff();
+        }
 
         uint32_t seen_sampled = 0;
         uint64_t t_wait = 0, t_work = 0, t_mark = STAMP ? (uint64_t)clock64() : 0;
@@ -433,8 +448,8 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 }
             }
             // reduce: the wave's smallest s', the lane that holds it, and the smallest among the other lanes
-            float k1v[kPassQ], k2v[kPassQ];   // valid in lane 63
-            int wl[kPassQ];
+            float k1v[kPassQ];   // valid in lane 63
+            uint32_t thw[kPassQ];
 #pragma unroll
             for (int b0 = 0; b0 < kPassQ; b0 += 4) {
                 float t4[4];
@@ -446,25 +461,19 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
 #pragma unroll
             for (int b = 0; b < kPassQ; ++b) {
-                const uint64_t eqm = __ballot(lf32_bits(b1[b]) == lf32_bits(lane63_f32(k1v[b])));
-                wl[b] = eqm ? __ffsll((unsigned long long)eqm) - 1 : 0;
-            }
-#pragma unroll
-            for (int b0 = 0; b0 < kPassQ; b0 += 4) {
-                float t4[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) t4[t] = (int)lane == wl[b0 + t] ? __builtin_inff() : b1[b0 + t];
-                lanes_min4_f32(t4);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) k2v[b0 + t] = t4[t];
+                const float k1u = lane63_f32(k1v[b]);
+                const uint64_t eqm = __ballot(lf32_bits(b1[b]) == lf32_bits(k1u));
+                const uint32_t wl = eqm ? (uint32_t)(__ffsll((unsigned long long)eqm) - 1) : 0u;
+                // one ballot instead of a second reduction: is any OTHER lane's smallest s' within 4E of the wave's?
+                const uint64_t nearm = __ballot(!(b1[b] > k1u + e4f));   // (k1u = +inf: every lane; NaN: every lane)
+                thw[b] = (wave * 64u + wl) | (__popcll(nearm) != 1 ? 0x80000000u : 0u);
             }
             if (lane == 63) {   // (records of the slots beyond a short last pass are never read)
 #pragma unroll
                 for (int b = 0; b < kPassQ; ++b) {
                     const uint32_t slot = (j + (uint32_t)b) & (kQRing - 1);
                     sh.pub_k1[wave][slot] = lf32_bits(k1v[b]);
-                    sh.pub_k2[wave][slot] = lf32_bits(k2v[b]);
-                    sh.pub_th[wave][slot] = wave * 64u + (uint32_t)wl[b];
+                    sh.pub_th[wave][slot] = thw[b];
                 }
                 sh.pub_nc[wave][((j & (kQRing - 1)) / (uint32_t)kPassQ) & (kQRing / 4 - 1)] = nc;
             }
@@ -683,7 +692,6 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
             for (int w = 0; w < kScanWaves; ++w) {
                 rec[w].k1 = sh.pub_k1[w][slot];
-                rec[w].k2 = sh.pub_k2[w][slot];
                 rec[w].th = sh.pub_th[w][slot];
                 rec[w].nc = sh.pub_nc[w][(slot / (uint32_t)kPassQ) & (kQRing / 4 - 1)];
             }
@@ -696,15 +704,28 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
             for (int w = 0; w < kScanWaves; ++w) {
                 const bool win = !taken && lbits_f32(rec[w].k1) == K1;   // the first wave attaining the minimum
-                K2 = fminf(K2, lbits_f32(win ? rec[w].k2 : rec[w].k1));
+                K2 = win ? K2 : fminf(K2, lbits_f32(rec[w].k1));         // K2: the smallest s' of the OTHER waves
                 wth = win ? rec[w].th : wth;
                 taken = taken || win;
             }
         }
         if (__ballot(act && (n - bmin > (uint32_t)(kNRing - 64) || bmin > n)) != 0) { stop = 4; break; }  // ring would have wrapped (bug guard)
+        const uint32_t wthread = wth & 0x1FFu;   // (bit 31 of the record: the wave could not separate its two best lanes)
         // the winning scanner lane's own nodes, in binary64 from the tree (four consecutive nodes per block of rows), then
         // the nodes committed after the oldest snapshot, from the LDS ring: ascending indices, so ties keep the lower index
         Scan pd{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
+        // The whole-tree path's last answer (below) is the exact nearest node of ITS query for the tree as it was then: a lane
+        // with that very query -- the goal centre, drawn again and again: when the screen cannot decide it once it cannot the
+        // next time either -- starts from that answer and only has to look at the nodes committed since (they are in the LDS
+        // ring), instead of ending the round's prefix and scanning the whole tree every time.
+        bool from_memo = act && memo_n <= n && n - memo_n <= (uint32_t)(kNRing - 64);
+#pragma unroll
+        for (int k = 0; k < D; ++k) from_memo = from_memo && __double_as_longlong(q[k]) == __double_as_longlong(memo_q[k]);
+        if (from_memo) {
+            pd.b1 = memo_g; pd.slot = memo_idx;   // (stored only when the minimum was unique: no second node within a rounding)
+            bmin = memo_n;
+        }
+        if (STAMP) n_memo += (uint64_t)__popcll(__ballot(from_memo));
         // (two blocks per trip: the tree of a whole batch does not fit the L2, a trip is a memory round trip)
 #pragma unroll
         for (int blk0 = 0; blk0 < S / 4; blk0 += 2) {
@@ -712,8 +733,8 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             bool have2[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                ib2[h] = blk0 + h < S / 4 ? Lay::block_base(wth, (uint32_t)(blk0 + h)) : kNoNode;
-                have2[h] = act && ib2[h] < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
+                ib2[h] = blk0 + h < S / 4 ? Lay::block_base(wthread, (uint32_t)(blk0 + h)) : kNoNode;
+                have2[h] = act && !from_memo && ib2[h] < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
                 il2[h] = have2[h] ? ib2[h] : 0u;
             }
             if (__ballot(have2[0] || have2[1]) == 0) continue;       // a small tree fills the first blocks only
@@ -792,20 +813,21 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
         }
         OXHIP_PHASE(1);   // ring fold
-        // accept iff every node this lane did not look at -- the other scanner lanes' -- is provably farther:
-        //   d_other^2 >= K2 + |b|^2 - E   >   g
-        bool clear = act && mg.usable && pd.slot != kNoNode && (pd.b1 < (double)K2 + bb - mg.e2);   // (NaN on either side: false)
-        // The whole-tree path's last answer (below) stands while the tree has not grown: a lane with that very query -- the
-        // goal centre, drawn again and again -- takes it here instead of ending the round's prefix every time.
+        // accept iff every node this lane did not look at -- the other scanner lanes' -- is provably farther: their smallest s'
+        // exceed K1 + 2.25 E (other waves: K2; the winning wave's other lanes: its own 2.5 E ballot) and g <= K1 + |b|^2 + E, hence
+        //   d_other^2 >= s'_other + |b|^2 - E  >  K1 + |b|^2 + 1.25 E  >=  g + E / 4
+        bool clear = act && mg.usable && pd.slot != kNoNode && (wth & 0x80000000u) == 0 &&
+                     ((double)K2 > (double)K1 + 1.125 * mg.e2) && (pd.b1 <= (double)K1 + bb + 0.5 * mg.e2);   // (NaN anywhere: false)
+        clear = clear || from_memo;   // (the memoized answer + the fold over everything committed since = the whole tree)
         {
-            bool same_q = act && memo_n == n && !(clear && pd.h2 > hi32(pd.b1) + 1);
-#pragma unroll
-            for (int k = 0; k < D; ++k) same_q = same_q && __double_as_longlong(q[k]) == __double_as_longlong(memo_q[k]);
-            if (same_q) {
-                pd.b1 = memo_g; pd.slot = memo_idx; pd.h2 = 0xFFFFFFFFu;   // (stored only when the minimum was unique)
-                clear = true;
+            // keep the answer current: the first such lane's result holds for the tree of n nodes
+            const uint64_t mm_ = __ballot(from_memo && pd.h2 > hi32(pd.b1) + 1);
+            if (mm_ != 0) {
+                const int ml = __ffsll((unsigned long long)mm_) - 1;
+                memo_g = readlane_f64(pd.b1, ml);
+                memo_idx = (uint32_t)__builtin_amdgcn_readlane((int)pd.slot, ml);
+                memo_n = n;
             }
-            if (STAMP) n_memo += (uint64_t)__popcll(__ballot(same_q));
         }
         const double g = pd.b1;
         const uint32_t hb = hi32(g) + 1;
@@ -868,8 +890,10 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                         if (j0 + (uint32_t)t < m) {
                             const uint32_t jl = uni(j0 + (uint32_t)t);
                             // (one scalar operand per VALU instruction on gfx9: the lane select goes through M0)
-                            asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
-                                : "+v"(maybe_lo), "+v"(maybe_hi) : "s"((uint32_t)mk[t]), "s"(jl), "s"((uint32_t)(mk[t] >> 32)) : "m0");
+                            // (M0 is the compiler's: saved and restored around its use)
+                            uint32_t m0_saved;
+                            asm volatile("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %4\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %5, m0\n\ts_mov_b32 m0, %2"
+                                         : "+v"(maybe_lo), "+v"(maybe_hi), "=&s"(m0_saved) : "s"((uint32_t)mk[t]), "s"(jl), "s"((uint32_t)(mk[t] >> 32)));
                         }
                     }
                 }
@@ -1226,6 +1250,12 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         st.draws = draws_done;
         st.stop_reason = stop;
         p.state[prob] = st;
+        if (STAMP && p.dbg) {   // over all problems: the largest exact-path count (with its problem id) and lifetime, and the sums
+            atomicMax((unsigned long long*)&p.dbg[44], (unsigned long long)((n_amb << 32) | prob));
+            atomicAdd((unsigned long long*)&p.dbg[45], (unsigned long long)n_amb);
+            atomicMax((unsigned long long*)&p.dbg[46], (unsigned long long)((((uint64_t)clock64() - t_begin) << 16) | (prob & 0xFFFFu)));
+            atomicAdd((unsigned long long*)&p.dbg[47], (unsigned long long)((uint64_t)clock64() - t_begin));
+        }
         if (STAMP && p.dbg && prob == 0) {
             p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_exact; p.dbg[15] = n_tie; p.dbg[11] = n_memo;
             for (int i = 0; i < 8; ++i) p.dbg[32 + i] = t_ph[i];

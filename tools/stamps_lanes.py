@@ -25,6 +25,9 @@ PH = ("combine+candidates", "ring fold", "coords+steer", "sphere filter", "motio
 print("  resolver phases, cycles per round:", ", ".join("%s %.0f" % (nm, int(s[32 + i]) / max(1, int(s[5]))) for i, nm in enumerate(PH)))
 print("  per round: ring-fold trips of eight %.1f, nodes that needed binary64 %.1f; conflict trips %.1f, exact tests %.1f"
       % tuple(int(s[40 + i]) / max(1, int(s[5])) for i in range(4)))
+print("  over all problems: exact-path events max %d (problem %d), mean %.1f; resolver lifetime max %.0f k cycles (problem %d), mean %.0f k"
+      % (int(s[44]) >> 32, int(s[44]) & 0xFFFFFFFF, int(s[45]) / P, (int(s[46]) >> 16) / 1e3, int(s[46]) & 0xFFFF, int(s[47]) / P / 1e3))
+gpu.enable_stamps(True)   # (resets the cross-problem accumulators)
 gpu.solve(iters, freeze=True)
 s2 = gpu.stamps()
 it = int(s2[7]) - int(s[7])
@@ -37,3 +40,5 @@ print("resolver lifetime: %d cycles in %.3f ms (100 MHz clock) = %.2f GHz; exact
       % (int(s2[13]), int(s2[14]) / 1e5, int(s2[13]) / max(1, int(s2[14])) / 10.0, int(s2[3]) / it, int(s2[3]) / max(1, int(s2[4]))))
 print("literal-loop (true near-tie) events: %d; whole-tree answers reused: %d" % (int(s2[15]), int(s2[11])))
 print("resolver phases, cycles per round:", ", ".join("%s %.0f" % (nm, int(s2[32 + i]) / max(1, int(s2[5]))) for i, nm in enumerate(PH)))
+print("over all problems: exact-path events max %d (problem %d), mean %.1f; resolver lifetime max %.0f k cycles (problem %d), mean %.0f k"
+      % (int(s2[44]) >> 32, int(s2[44]) & 0xFFFFFFFF, int(s2[45]) / P, (int(s2[46]) >> 16) / 1e3, int(s2[46]) & 0xFFFF, int(s2[47]) / P / 1e3))
