@@ -466,7 +466,11 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 const uint32_t wl = eqm ? (uint32_t)(__ffsll((unsigned long long)eqm) - 1) : 0u;
                 // one ballot instead of a second reduction: is any OTHER lane's smallest s' within 4E of the wave's?
                 const uint64_t nearm = __ballot(!(b1[b] > k1u + e4f));   // (k1u = +inf: every lane; NaN: every lane)
-                thw[b] = (wave * 64u + wl) | (__popcll(nearm) != 1 ? 0x80000000u : 0u);
+                const int nnear = __popcll(nearm);
+                // exactly one other lane: name it (bits 16..21, bit 30), the resolver then looks at both lanes' nodes
+                const uint64_t otherm = nearm & ~(1ull << wl);
+                const uint32_t ol = (nnear == 2 && otherm != 0) ? (0x40000000u | ((uint32_t)(__ffsll((unsigned long long)otherm) - 1) << 16)) : 0u;
+                thw[b] = (wave * 64u + wl) | (nnear != 1 ? 0x80000000u : 0u) | ol;
             }
             if (lane == 63) {   // (records of the slots beyond a short last pass are never read)
 #pragma unroll
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     uint32_t n = st.n_nodes;
     uint32_t jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
-    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, n_fold_trips = 0, n_fold_exact = 0, n_conf_trips = 0, n_conf_exact = 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = STAMP ? (uint64_t)clock64() : 0;
+    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, n_pair = 0, n_fold_trips = 0, n_fold_exact = 0, n_conf_trips = 0, n_conf_exact = 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = STAMP ? (uint64_t)clock64() : 0;
     const uint64_t t_begin = t_mark, rt_begin = STAMP ? (uint64_t)__builtin_amdgcn_s_memrealtime() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
@@ -685,8 +689,8 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         // this wave's own earlier stores to the tree have reached the cache the loads below read (same CU; a wait, no cache op)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         // the eight waves' screens: the scanner lane that holds the smallest s', the smallest s' of every other lane, oldest snapshot
-        float K1 = __builtin_inff(), K2 = __builtin_inff();
-        uint32_t wth = 0, bmin = 0xFFFFFFFFu;
+        float K1 = __builtin_inff(), K2 = __builtin_inff(), K3 = __builtin_inff();
+        uint32_t wth = 0, wth2 = 0, bmin = 0xFFFFFFFFu;
         {
             LanePub rec[kScanWaves];
 #pragma unroll
@@ -701,12 +705,23 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 bmin = rec[w].nc < bmin ? rec[w].nc : bmin;
             }
             bool taken = false;
+            uint32_t w1 = 0;
 #pragma unroll
             for (int w = 0; w < kScanWaves; ++w) {
                 const bool win = !taken && lbits_f32(rec[w].k1) == K1;   // the first wave attaining the minimum
                 K2 = win ? K2 : fminf(K2, lbits_f32(rec[w].k1));         // K2: the smallest s' of the OTHER waves
                 wth = win ? rec[w].th : wth;
+                w1 = win ? (uint32_t)w : w1;
                 taken = taken || win;
+            }
+            // the runner-up wave and K3, the smallest s' of the remaining six
+            taken = false;
+#pragma unroll
+            for (int w = 0; w < kScanWaves; ++w) {
+                const bool second = !taken && (uint32_t)w != w1 && lbits_f32(rec[w].k1) == K2;
+                K3 = (second || (uint32_t)w == w1) ? K3 : fminf(K3, lbits_f32(rec[w].k1));
+                wth2 = second ? rec[w].th : wth2;
+                taken = taken || second;
             }
         }
         if (__ballot(act && (n - bmin > (uint32_t)(kNRing - 64) || bmin > n)) != 0) { stop = 4; break; }  // ring would have wrapped (bug guard)
@@ -726,15 +741,32 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             bmin = memo_n;
         }
         if (STAMP) n_memo += (uint64_t)__popcll(__ballot(from_memo));
+        // When the screen leaves exactly TWO scanner lanes in question -- the winner and one other lane of its wave (named in
+        // the record), or the winners of two waves with every third wave out of reach -- both lanes' nodes are looked at, which
+        // again covers every node whose s' is within 2.25 E of K1; only three-way cases go to the whole-tree path.
+        const double m225 = (double)K1 + 1.125 * mg.e2;
+        const bool flag1 = (wth & 0x80000000u) != 0, waves_out = (double)K2 > m225;   // (NaN / inf: false)
+        uint32_t wthread2 = 0xFFFFFFFFu;
+        if (waves_out && (wth & 0x40000000u) != 0) wthread2 = (wth & 0x1C0u) | ((wth >> 16) & 63u);
+        else if (!flag1 && !waves_out && (double)K3 > m225 && (wth2 & 0x80000000u) == 0) wthread2 = wth2 & 0x1FFu;
+        const bool pair = act && !from_memo && mg.usable && wthread2 != 0xFFFFFFFFu;
         // (two blocks per trip: the tree of a whole batch does not fit the L2, a trip is a memory round trip)
+#pragma nounroll
+        for (int cpass = 0; cpass < 2; ++cpass) {   // (a tie between the two lanes' nodes is flagged by scan_push whatever the order)
+        if (cpass == 1) {
+            if (__ballot(pair) == 0) break;
+            if (STAMP) ++n_pair;
+        }
+        const uint32_t thread_ = cpass == 0 ? wthread : (pair ? wthread2 : 0u);
+        const bool on_ = cpass == 0 ? (act && !from_memo) : pair;
 #pragma unroll
         for (int blk0 = 0; blk0 < S / 4; blk0 += 2) {
             uint32_t ib2[2], il2[2], sk2[2];
             bool have2[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                ib2[h] = blk0 + h < S / 4 ? Lay::block_base(wthread, (uint32_t)(blk0 + h)) : kNoNode;
-                have2[h] = act && !from_memo && ib2[h] < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
+                ib2[h] = blk0 + h < S / 4 ? Lay::block_base(thread_, (uint32_t)(blk0 + h)) : kNoNode;
+                have2[h] = on_ && ib2[h] < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
                 il2[h] = have2[h] ? ib2[h] : 0u;
             }
             if (__ballot(have2[0] || have2[1]) == 0) continue;       // a small tree fills the first blocks only
@@ -763,6 +795,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 for (int t = 0; t < 4; ++t)
                     if (have2[h] && ib2[h] + (uint32_t)t < bmin && ((sk2[h] >> (8 * t)) & 0xFFu) == 0) scan_push(pd, d8[h][t], ib2[h] + (uint32_t)t);
             }
+        }
         }
         OXHIP_PHASE(0);   // combine + the winning lane's candidates
         // this lane's query as the screens see it: Q = -2 fl32(q - c0), |b|^2
@@ -816,8 +849,8 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         // accept iff every node this lane did not look at -- the other scanner lanes' -- is provably farther: their smallest s'
         // exceed K1 + 2.25 E (other waves: K2; the winning wave's other lanes: its own 2.5 E ballot) and g <= K1 + |b|^2 + E, hence
         //   d_other^2 >= s'_other + |b|^2 - E  >  K1 + |b|^2 + 1.25 E  >=  g + E / 4
-        bool clear = act && mg.usable && pd.slot != kNoNode && (wth & 0x80000000u) == 0 &&
-                     ((double)K2 > (double)K1 + 1.125 * mg.e2) && (pd.b1 <= (double)K1 + bb + 0.5 * mg.e2);   // (NaN anywhere: false)
+        bool clear = act && mg.usable && pd.slot != kNoNode && ((!flag1 && waves_out) || pair) &&
+                     (pd.b1 <= (double)K1 + bb + 0.5 * mg.e2);   // (NaN anywhere: false)
         clear = clear || from_memo;   // (the memoized answer + the fold over everything committed since = the whole tree)
         {
             // keep the answer current: the first such lane's result holds for the tree of n nodes
@@ -1255,6 +1288,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             atomicAdd((unsigned long long*)&p.dbg[45], (unsigned long long)n_amb);
             atomicMax((unsigned long long*)&p.dbg[46], (unsigned long long)((((uint64_t)clock64() - t_begin) << 16) | (prob & 0xFFFFu)));
             atomicAdd((unsigned long long*)&p.dbg[47], (unsigned long long)((uint64_t)clock64() - t_begin));
+            atomicAdd((unsigned long long*)&p.dbg[48], (unsigned long long)n_pair);
         }
         if (STAMP && p.dbg && prob == 0) {
             p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_exact; p.dbg[15] = n_tie; p.dbg[11] = n_memo;

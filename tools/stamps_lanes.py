@@ -27,6 +27,7 @@ print("  per round: ring-fold trips of eight %.1f, nodes that needed binary64 %.
       % tuple(int(s[40 + i]) / max(1, int(s[5])) for i in range(4)))
 print("  over all problems: exact-path events max %d (problem %d), mean %.1f; resolver lifetime max %.0f k cycles (problem %d), mean %.0f k"
       % (int(s[44]) >> 32, int(s[44]) & 0xFFFFFFFF, int(s[45]) / P, (int(s[46]) >> 16) / 1e3, int(s[46]) & 0xFFFF, int(s[47]) / P / 1e3))
+print("  rounds with a two-lane candidate pass: mean %.1f per problem" % (int(s[48]) / P))
 gpu.enable_stamps(True)   # (resets the cross-problem accumulators)
 gpu.solve(iters, freeze=True)
 s2 = gpu.stamps()
@@ -42,3 +43,4 @@ print("literal-loop (true near-tie) events: %d; whole-tree answers reused: %d" %
 print("resolver phases, cycles per round:", ", ".join("%s %.0f" % (nm, int(s2[32 + i]) / max(1, int(s2[5]))) for i, nm in enumerate(PH)))
 print("over all problems: exact-path events max %d (problem %d), mean %.1f; resolver lifetime max %.0f k cycles (problem %d), mean %.0f k"
       % (int(s2[44]) >> 32, int(s2[44]) & 0xFFFFFFFF, int(s2[45]) / P, (int(s2[46]) >> 16) / 1e3, int(s2[46]) & 0xFFFF, int(s2[47]) / P / 1e3))
+print("rounds with a two-lane candidate pass: mean %.1f per problem" % (int(s2[48]) / P))
