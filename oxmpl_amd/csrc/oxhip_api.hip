@@ -7,6 +7,7 @@
 // entry point that computes returns OXHIP_ERR_NO_DEVICE.
 #include "../../include/oxmpl_hip.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -153,6 +154,11 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.res = res;
     dp.p_int = bernoulli_p_int(cfg->goal_bias);
     dp.seed = cfg->seed;
+    {   // diagnosis / regression tests only: OXHIP_DEBUG_FLAGS bit 0 = the lane-per-query kernel sends two-lane cases to its
+        // whole-tree path as well (that path is otherwise reached by three-way near-ties only)
+        const char* e = std::getenv("OXHIP_DEBUG_FLAGS");
+        dp.dbg_flags = e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u;
+    }
     dp.first_problem_id = cfg->first_problem_id;
     dp.stop_at_goal = cfg->stop_at_goal ? 1 : 0;
     dp.t_steer = sqrt_le_threshold(cfg->max_distance);

@@ -51,6 +51,12 @@ constexpr int kNRing = 256;                         // committed nodes kept in L
 #define OXHIP_LANES_PASS3 8
 #endif
 template <int DIM> struct LanesPass { static constexpr int Q = DIM >= 6 ? 4 : (DIM <= 3 ? OXHIP_LANES_PASS3 : 8); };   // queries one scanner pass covers (register budget)
+#ifndef OXHIP_LANES_PAIR
+#define OXHIP_LANES_PAIR 1            // 0: (diagnosis) two-lane cases go to the whole-tree path like three-way ones
+#endif
+#ifndef OXHIP_LANES_TRANSPOSE_MAX
+#define OXHIP_LANES_TRANSPOSE_MAX 32  // rounds of at most this many lanes use the transposed sphere pre-filter (0: never)
+#endif
 #ifndef OXHIP_DEPTH_GROW
 #define OXHIP_DEPTH_GROW 64
 #endif
@@ -749,7 +755,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         uint32_t wthread2 = 0xFFFFFFFFu;
         if (waves_out && (wth & 0x40000000u) != 0) wthread2 = (wth & 0x1C0u) | ((wth >> 16) & 63u);
         else if (!flag1 && !waves_out && (double)K3 > m225 && (wth2 & 0x80000000u) == 0) wthread2 = wth2 & 0x1FFu;
-        const bool pair = act && !from_memo && mg.usable && wthread2 != 0xFFFFFFFFu;
+        const bool pair = OXHIP_LANES_PAIR && (p.dbg_flags & 1u) == 0 && act && !from_memo && mg.usable && wthread2 != 0xFFFFFFFFu;
         // (two blocks per trip: the tree of a whole batch does not fit the L2, a trip is a memory round trip)
 #pragma nounroll
         for (int cpass = 0; cpass < 2; ++cpass) {   // (a tie between the two lanes' nodes is flagged by scan_push whatever the order)
@@ -882,6 +888,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         OXHIP_PHASE(2);   // nearest node's coordinates + steer
         // check_motion (rrt.rs:90-116): the midpoint filter names the spheres the segment can touch at all ...
         bool bad = false;
+        uint64_t maybe_dbg = 0;
         if (nobs > 0) {
             lerp<DIM>(q_near, qn, 0.5, mid, DIM);
             // (binary32 first: a sphere whose screen value proves d2(centre, mid) > filter threshold is cleared after D fused
@@ -899,7 +906,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 mm = (float)(mmd * (1.0 - 0x1p-22));   // rounded down: errs towards "maybe"
             }
             uint32_t maybe_lo = 0, maybe_hi = 0;
-            if (m <= 32u) {
+            if (m <= (uint32_t)OXHIP_LANES_TRANSPOSE_MAX) {
             // Small rounds (growing trees), transposed: lane s holds sphere s; the round's midpoints are staged in LDS and visited
             // one by one (wave-uniform reads, four per trip), each costing D fused multiply-adds, an add, a compare (= the
             // 64-sphere mask of that query) and two v_writelane into the query's own lane -- a round of 10 lanes pays for 10
@@ -964,6 +971,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
             const uint64_t maybe = ((uint64_t)maybe_hi << 32) | maybe_lo;
             OXHIP_PHASE(3);   // sphere filter
+            if (STAMP) maybe_dbg = maybe;
             const bool need = act && !amb && (maybe != 0 || extras);
             if (__ballot(need) != 0) {
                 // ... and every lane steps through its own motion against just those (is_valid is pure: testing all states
@@ -999,6 +1007,22 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
         }
         OXHIP_PHASE(4);   // motion check
+        if (STAMP && p.dbg) {   // audit (diagnostic instantiation only): an accepted motion whose end state lies inside one of the first 64 spheres
+            bool inval = false;
+            for (uint32_t o = 0; o < ns64; ++o) {
+                double c[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) c[k] = sh.obs[k][o];
+                inval = inval || !(dist2<D>(c, qn, DIM) > sh.obs[D][o]);
+            }
+            const uint64_t badm = __ballot(act && !amb && !bad && inval);
+            if (badm != 0 && lane == (uint32_t)(__ffsll((unsigned long long)badm) - 1)) {
+                atomicAdd((unsigned long long*)&p.dbg[50], 1ull);
+                p.dbg[51] = ((uint64_t)prob << 48) | ((uint64_t)m << 40) | ((uint64_t)lane << 32) | (st.iterations + lane);
+                p.dbg[52] = ((uint64_t)maybe_dbg);
+                p.dbg[53] = 1;
+            }
+        }
         const bool ok = act && !bad;
         const bool ins = !p.freeze;
         // this lane's new node as the scanners (and the binary32 screens) will hold it
@@ -1240,6 +1264,15 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 lerp<DIM>(q_near1, qn1, 0.5, mid1, DIM);
                 if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid1)) != 0 || extras)
                     ok1 = motion_lanes<DIM>(p, lane, q_near1, qn1, oc, othr, ofilt, ns64);
+            }
+            if (STAMP && p.dbg) {   // the same audit for the one-query path
+                const bool inval1 = lane < ns64 && !(dist2<D>(oc, qn1, DIM) > othr);
+                if (ok1 && __ballot(inval1) != 0 && lane == 0) {
+                    atomicAdd((unsigned long long*)&p.dbg[50], 1ull);
+                    p.dbg[51] = ((uint64_t)prob << 48) | st.iterations;
+                    p.dbg[52] = __ballot(inval1);
+                    p.dbg[53] = 2 | (tie ? 4 : 0) | (same_q ? 8 : 0);
+                }
             }
             st.checksum = uni64(chk_push(st.checksum, iter_digest<D>(nearest1, qn1, DIM, ok1)));
             st.iterations++;

@@ -246,7 +246,11 @@ __device__ __forceinline__ bool motion_lanes(const DevParams& p, uint32_t lane, 
             double c[DIM];
 #pragma unroll
             for (int k = 0; k < DIM; ++k) c[k] = readlane_f64(oc[k], j);
-            bad = bad || (act && !(dist2<DIM>(c, x, DIM) > readlane_f64(othr, j)));
+            // (read across lanes OUTSIDE the short-circuit below: sphere j's own lane is usually not one of the lanes with a
+            // step to test, and a cross-lane read under their narrower exec mask returns whatever the register allocator left
+            // in lane j -- with `othr` spilled, as in the R^4..R^6 lane-per-query kernels, a stale temporary)
+            const double thr_j = readlane_f64(othr, j);
+            bad = bad || (act && !(dist2<DIM>(c, x, DIM) > thr_j));
         }
         for (uint32_t j = ns64; j < nobs; ++j) bad = bad || (act && obstacle_hit<DIM>(p, DIM, x, j));
         if (__ballot(bad) != 0) break;

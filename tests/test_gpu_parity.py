@@ -310,6 +310,49 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
         gpu.close()
 
 
+@pytest.mark.parametrize("mode", ["product", "whole_tree_path_forced", "whole_tree_path_forced_diagnostic_build"])
+@pytest.mark.parametrize("kernel", [capi.KERNEL_LANES, capi.KERNEL_STREAM], ids=lambda k: KNAME[k])
+def test_fuzz_seed203_r6_case(kernel, mode, monkeypatch):
+    """The one mismatch tools/fuzz_parity.py found this round (seed 203, committed as a fixture with the obstacle field it drew):
+    R^6, 100 spheres, 9 problems grown to 9000 nodes.  In problem 2, iteration 5868, two nodes are 4.5 apart in d2 at
+    E = 2.4: the lane-per-query kernel of that build sent the query to its whole-tree path, whose wave-wide motion check read
+    sphere 5's threshold across lanes from inside a divergent region -- with the register spilled (R^4..R^6), lane 5 held a
+    stale temporary and an end state inside the sphere was accepted.  OXHIP_DEBUG_FLAGS=1 sends two-lane cases down that
+    path again (the product build resolves them in the round), so the path stays covered -- in the product instantiation
+    and in the diagnostic one (stamps on), whose audit counts accepted end states that lie inside a sphere."""
+    import json
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_r6_seed203_case.npz"))
+    d = json.loads(str(z["desc"]))
+    no_pair, stamped = mode != "product", mode.endswith("diagnostic_build")
+    if no_pair:
+        if kernel != capi.KERNEL_LANES:
+            pytest.skip("the switch concerns the lane-per-query kernel only")
+        monkeypatch.setenv("OXHIP_DEBUG_FLAGS", "1")
+    dim = d["dim"]
+    bounds = [(d["lo"], d["hi"])] * dim
+    gpu = capi.RRTBatch(dim, bounds, d["md"], d["gb"], d["nprob"], d["max_nodes"], d["frac"], d["stop"], d["seed"], d["pid0"], 0, kernel)
+    gpu.set_spheres(z["sc"], z["sr"])
+    gpu.setup(z["start"], z["goal"], float(z["gr"]))
+    if stamped:
+        gpu.enable_stamps(True)
+    for a in z["schedule"]:
+        gpu.solve(int(a))
+    planners = []
+    for p in range(d["nprob"]):
+        o = orc.OracleRRT(dim, bounds, d["md"], d["gb"], d["frac"], d["max_nodes"], d["stop"], d["seed"], d["pid0"] + p)
+        o.set_spheres(z["sc"], z["sr"])
+        o.setup(z["start"], z["goal"], float(z["gr"]))
+        planners.append(o)
+    orc.solve_many(planners, int(sum(z["schedule"])), threads=9)
+    c = gpu.counts()
+    for p in range(d["nprob"]):
+        _assert_same_problem(gpu, p, planners[p], c)
+    if stamped:
+        assert int(gpu.stamps()[50]) == 0          # the diagnostic build's audit: no accepted end state inside a sphere
+        assert int(gpu.stamps()[4]) > 0            # workgroup 0 did take the whole-tree path
+    gpu.close()
+
+
 @pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
 def test_long_motion_checks_are_not_a_stalled_pipeline(kernel):
     """A tiny longest-valid-segment fraction makes every motion check 300,000 interpolated states against 48 boxes

@@ -15,6 +15,7 @@ from oracle import oracle_py as orc  # noqa: E402
 BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 counts, failures = {}, []
+DUMP_DIR = os.environ.get("FUZZ_DUMP_DIR", "")
 
 
 def bits(a):
@@ -73,16 +74,19 @@ def case_rv(planner):
     if len(blo):
         g.set_boxes(blo, bhi)
     g.setup(start, goal, gr)
+    schedule = []
     if rng.random() < 0.4:                      # the same budget in two or three solve calls (resume)
         a = int(rng.integers(1, iters))
-        g.solve(a)
+        schedule.append(a)
         if rng.random() < 0.5 and iters - a > 1:
             b = int(rng.integers(1, iters - a))
-            g.solve(b)
+            schedule.append(b)
             a += b
-        g.solve(iters - a)
+        schedule.append(iters - a)
     else:
-        g.solve(iters)
+        schedule.append(iters)
+    for a in schedule:
+        g.solve(a)
     frozen = int(rng.choice([0, 0, 64, 700, 3000])) if planner == capi.PLANNER_RRT else 0   # then some iterations with inserts off
     if frozen:
         g.solve(frozen, freeze=True)
@@ -119,7 +123,11 @@ def case_rv(planner):
         gpath, opath = g.path(p), o.path()
         ok = ok and gpath.shape == opath.shape and np.array_equal(bits(gpath), bits(opath))
         if not ok:
-            return dict(desc, problem=p)
+            if DUMP_DIR:   # everything tools/fuzz_replay.py needs to run the case again
+                os.makedirs(DUMP_DIR, exist_ok=True)
+                np.savez(os.path.join(DUMP_DIR, "fuzz_fail_%d_%d.npz" % (seed, pid0)), desc=json.dumps(desc), sc=sc, sr=sr, blo=blo, bhi=bhi,
+                         start=start, goal=goal, gr=gr, schedule=np.array(schedule, dtype=np.int64), frozen=frozen, problem=p)
+            return dict(desc, problem=p, schedule=schedule, frozen=frozen)
     g.close()
     return True
 
