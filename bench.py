@@ -51,19 +51,19 @@ def valu_peak(kname):
     divided by the 160 rows of a 10,240-slot tree.  resident (binary64 scanners): tools/scan_bench.hip, 1.0 us per
     10k-node scan per CU (profiles/r1_resident)."""
     if kname == "lanes":
-        # the dot-product screen: D packed fused multiply-adds per query pair + one v_min_f32 per query and 64-node register
-        # row (2.5 instructions per row and query), 24 rows, two waves per SIMD as in the kernel; a 10,000-node tree occupies
+        # the dot-product screen: D packed fused multiply-adds per PAIR of 64-node register rows and query + one v_min3_f32
+        # (2.0 instructions per row and query in R^3), 24 rows, two waves per SIMD as in the kernel; a 10,000-node tree occupies
         # 160 rows across the eight scanner waves (blocks of four rows)
         try:
             with open(os.path.join(ROOT, "profiles", "r2_valu_peak.json")) as f:
                 d = json.load(f)
-            for e in d["dot_screen"]:
-                if e["dim"] == 3 and e["rows"] == 24 and e["waves_per_simd"] == 2:
+            for e in d["dot_screen_min3"]:
+                if e["dim"] == 3 and e["rows"] == 24 and e["waves_per_simd"] == 2 and e["queries_per_pass"] == 8:
                     return e["row_queries_per_s_chip"] / ROWS_PER_ITERATION, \
-                        "profiles/r2_valu_peak.json: dot_screen, R^3, 24 rows, 2 waves/SIMD, / 160 rows per iteration"
+                        "profiles/r2_valu_peak.json: dot_screen_min3, R^3, 24 rows, 2 waves/SIMD, / 160 rows per iteration"
         except (OSError, KeyError, ValueError):
             pass
-        return None, "profiles/r2_valu_peak.json has no dot_screen entry"
+        return None, "profiles/r2_valu_peak.json has no dot_screen_min3 entry"
     if kname == "resident_f32":
         try:
             with open(os.path.join(ROOT, "profiles", "r2_valu_peak.json")) as f:

@@ -39,6 +39,7 @@
 #include "oxhip_internal.hpp"
 #include "rrt_device.hpp"
 #include "rrt_resident_common.hpp"
+#include "lanes_reduce.hpp"
 
 namespace oxhip {
 
@@ -142,30 +143,11 @@ struct LanesShared {
 __device__ __forceinline__ uint32_t lf32_bits(float v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ __forceinline__ float lbits_f32(uint32_t v) { return __builtin_bit_cast(float, v); }
 
-// wave-wide float minima of four independent values, one v_min_f32_dpp per value and step (the four chains interleave, so a
-// value's next step is three instructions behind its last write: no hazard padding beyond the leading s_nop).  Lanes a
-// step gives no source keep their value.  The values are finite or +inf (never NaN: see the scanner).
-#define OXHIP_LMIN4_STEP(ctrl)                  \
-    "v_min_f32_dpp %0, %0, %0 " ctrl "\n"       \
-    "v_min_f32_dpp %1, %1, %1 " ctrl "\n"       \
-    "v_min_f32_dpp %2, %2, %2 " ctrl "\n"       \
-    "v_min_f32_dpp %3, %3, %3 " ctrl "\n"
-__device__ __forceinline__ void lanes_min4_f32(float (&v)[4]) {
-    float a = v[0], b = v[1], c = v[2], d = v[3];
-    asm("s_nop 1\n"
-        OXHIP_LMIN4_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-        OXHIP_LMIN4_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-        OXHIP_LMIN4_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
-        OXHIP_LMIN4_STEP("row_mirror row_mask:0xf bank_mask:0xf")
-        OXHIP_LMIN4_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-        OXHIP_LMIN4_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
-        : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    v[0] = a; v[1] = b; v[2] = c; v[3] = d;   // lane 63 holds the four minima
-}
-__device__ __forceinline__ float lane63_f32(float v) { return lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(v), 63)); }
-#undef OXHIP_LMIN4_STEP
 __device__ __forceinline__ void vmin_f32(float& acc, float x) {   // plain v_min_f32 in place: no canonicalising v_max in front,
     asm("v_min_f32 %0, %0, %1" : "+v"(acc) : "v"(x));             // and no renamed register to copy back where branches join
+}
+__device__ __forceinline__ void vmin3_f32(float& acc, float x, float y) {   // acc = min(acc, x, y) in one issue slot (never NaN here)
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(acc) : "v"(x), "v"(y));
 }
 
 // wave-wide sum of a 64-bit value (mod 2^64); every lane of the last row holds it, lane 63 is read
@@ -433,61 +415,58 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             for (int g0 = 0; g0 < S; g0 += 4) {
                 if ((uint32_t)g0 < nrows) {
 #pragma unroll
-                    for (int s = g0; s < g0 + 4; ++s) {
-                        // the four query pairs' chains side by side: consecutive instructions are independent
-                        lf32x2 acc[kPassQ / 2];
+                    for (int sp = g0 / 2; sp < g0 / 2 + 2; ++sp) {
+                        // a packed fused multiply-add covers the two ROWS of a register pair for one query (op_sel broadcasts the
+                        // query's half of its pair) and one v_min3_f32 folds both rows into the query's minimum; four queries'
+                        // chains side by side, so consecutive instructions are independent
 #pragma unroll
-                        for (int bp = 0; bp < kPassQ / 2; ++bp)
-                            acc[bp] = (s & 1) ? __builtin_shufflevector(tcc[s / 2], tcc[s / 2], 1, 1) : __builtin_shufflevector(tcc[s / 2], tcc[s / 2], 0, 0);
+                        for (int b0 = 0; b0 < kPassQ; b0 += 4) {
+                            lf32x2 acc[4];
 #pragma unroll
-                        for (int k = 0; k < D; ++k) {
-                            const lf32x2 a = (s & 1) ? __builtin_shufflevector(tr[k][s / 2], tr[k][s / 2], 1, 1) : __builtin_shufflevector(tr[k][s / 2], tr[k][s / 2], 0, 0);
+                            for (int t = 0; t < 4; ++t) acc[t] = tcc[sp];
 #pragma unroll
-                            for (int bp = 0; bp < kPassQ / 2; ++bp) acc[bp] = __builtin_elementwise_fma(a, q[bp][k], acc[bp]);
-                        }
+                            for (int k = 0; k < D; ++k) {
 #pragma unroll
-                        for (int bp = 0; bp < kPassQ / 2; ++bp) {
-                            vmin_f32(b1[2 * bp], acc[bp][0]);
-                            vmin_f32(b1[2 * bp + 1], acc[bp][1]);
+                                for (int t = 0; t < 4; ++t) {
+                                    const lf32x2 qp = q[(b0 + t) / 2][k];
+                                    const lf32x2 qq = ((b0 + t) & 1) ? __builtin_shufflevector(qp, qp, 1, 1) : __builtin_shufflevector(qp, qp, 0, 0);
+                                    acc[t] = __builtin_elementwise_fma(tr[k][sp], qq, acc[t]);
+                                }
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) vmin3_f32(b1[b0 + t], acc[t][0], acc[t][1]);
                         }
                     }
                 }
             }
-            // reduce: the wave's smallest s', the lane that holds it, and the smallest among the other lanes
-            float k1v[kPassQ];   // valid in lane 63
-            uint32_t thw[kPassQ];
-#pragma unroll
-            for (int b0 = 0; b0 < kPassQ; b0 += 4) {
-                float t4[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) t4[t] = b1[b0 + t];
-                lanes_min4_f32(t4);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) k1v[b0 + t] = t4[t];
-            }
+            // reduce (lanes_reduce.hpp): all of the pass's wave minima in ONE register -- lanes 8b .. 8b + 7 hold query b's --
+            // 17 instructions for eight queries instead of eight 6-step reductions
+            const float u = lanes_min_transposed<kPassQ>(b1);
+            const float uthr = u + e4f;   // (+inf stays +inf; never NaN: see above)
+            // per query ONE ballot: which lanes' smallest s' are within 2.5 E of the wave's?  The lane that holds the minimum is
+            // always among them.  Exactly one: that lane, proven.  Exactly two: both are named (bits 0..8, bits 16..21 + bit 30) and
+            // the resolver looks at both lanes' nodes, in whichever order.  More: not proven (bit 31), the resolver's whole-tree path.
+            uint32_t thv = 0;
 #pragma unroll
             for (int b = 0; b < kPassQ; ++b) {
-                const float k1u = lane63_f32(k1v[b]);
-                const uint64_t eqm = __ballot(lf32_bits(b1[b]) == lf32_bits(k1u));
-                const uint32_t wl = eqm ? (uint32_t)(__ffsll((unsigned long long)eqm) - 1) : 0u;
-                // one ballot instead of a second reduction: is any OTHER lane's smallest s' within 4E of the wave's?
-                const uint64_t nearm = __ballot(!(b1[b] > k1u + e4f));   // (k1u = +inf: every lane; NaN: every lane)
+                const float thr = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(uthr), 8 * b));
+                const uint64_t nearm = __ballot(!(b1[b] > thr));   // (minimum +inf -- the wave holds no node yet -- : every lane)
                 const int nnear = __popcll(nearm);
-                // exactly one other lane: name it (bits 16..21, bit 30), the resolver then looks at both lanes' nodes
-                const uint64_t otherm = nearm & ~(1ull << wl);
-                const uint32_t ol = (nnear == 2 && otherm != 0) ? (0x40000000u | ((uint32_t)(__ffsll((unsigned long long)otherm) - 1) << 16)) : 0u;
-                thw[b] = (wave * 64u + wl) | (nnear != 1 ? 0x80000000u : 0u) | ol;
+                const uint32_t wl = nearm ? (uint32_t)(__ffsll((unsigned long long)nearm) - 1) : 0u;
+                const uint64_t otherm = nearm & (nearm - 1ull);
+                const uint32_t ol = (nnear == 2) ? (0x40000000u | ((uint32_t)(__ffsll((unsigned long long)otherm) - 1) << 16)) : 0u;
+                const uint32_t t = (wave * 64u + wl) | (nnear != 1 ? 0x80000000u : 0u) | ol;
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(thv) : "s"(t), "n"(8 * b));   // lane 8b <- the wave-uniform record
             }
-            if (lane == 63) {   // (records of the slots beyond a short last pass are never read)
-#pragma unroll
-                for (int b = 0; b < kPassQ; ++b) {
-                    const uint32_t slot = (j + (uint32_t)b) & (kQRing - 1);
-                    sh.pub_k1[wave][slot] = lf32_bits(k1v[b]);
-                    sh.pub_th[wave][slot] = thw[b];
-                }
+            if ((lane & 7u) == 0 && lane < 8u * (uint32_t)kPassQ) {   // lane 8b publishes query b (records of the slots beyond a short last pass are never read)
+                const uint32_t slot = (j + (lane >> 3)) & (kQRing - 1);
+                sh.pub_k1[wave][slot] = lf32_bits(u);
+                sh.pub_th[wave][slot] = thv;
+            }
+            if (lane == 0) {
                 sh.pub_nc[wave][((j & (kQRing - 1)) / (uint32_t)kPassQ) & (kQRing / 4 - 1)] = nc;
+                lds_post(&sh.wave_done[wave], need);   // after the records (LDS is in order within a wave)
             }
-            if (lane == 63) lds_post(&sh.wave_done[wave], need);   // after the records (LDS is in order within a wave)
             if (STAMP) { uint64_t now = (uint64_t)clock64(); t_work += now - t_mark; t_mark = now; }
         }
         if (STAMP && p.dbg && prob == 0 && lane == 0) { p.dbg[16 + wave] = t_wait; p.dbg[24 + wave] = t_work; }

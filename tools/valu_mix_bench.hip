@@ -23,9 +23,9 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kLdsPad = 84 * 1024;   // > half of 160 KB: one workgroup per CU
 
-enum Op { PK_FMA, PK_ADD, PK_MUL, AND_OR, MED3, MIN_U32, FMA_F32, ADD_F64, FMA_F64, MIN_F32, MED3_F32, N_OPS };
+enum Op { PK_FMA, PK_ADD, PK_MUL, AND_OR, MED3, MIN_U32, FMA_F32, ADD_F64, FMA_F64, MIN_F32, MED3_F32, MIN3_F32, N_OPS };
 static const char* kOpName[N_OPS] = {"v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_and_or_b32", "v_med3_u32", "v_min_u32",
-                                     "v_fma_f32", "v_add_f64", "v_fma_f64", "v_min_f32", "v_med3_f32"};
+                                     "v_fma_f32", "v_add_f64", "v_fma_f64", "v_min_f32", "v_med3_f32", "v_min3_f32"};
 
 // 16 independent destination registers (pairs), 4 rounds unrolled in the asm block = 64 instructions per block
 #define R16(INS)                                                                                                     \
@@ -110,6 +110,10 @@ __global__ void op32_kernel(uint64_t* cyc, uint32_t* sink, int iters) {
 #undef I
         } else if (OP == MED3_F32) {
 #define I(n) "v_med3_f32 %" #n ", %" #n ", %16, %17\n"
+            asm volatile(R16(I) R16(I) R16(I) R16(I) OPERANDS);
+#undef I
+        } else if (OP == MIN3_F32) {
+#define I(n) "v_min3_f32 %" #n ", %" #n ", %16, %17\n"
             asm volatile(R16(I) R16(I) R16(I) R16(I) OPERANDS);
 #undef I
         }
@@ -210,7 +214,10 @@ __global__ __launch_bounds__(NT) void screen_kernel(const float* pts, uint64_t* 
 
 // ---- the dot-product screen of rrt_lanes.hip: a node is (a, cc = |a|^2), a query Q = -2 b, s' = cc + a . Q: D packed fused
 // multiply-adds per (row, query pair) and one v_min_f32 per (row, query) -- 2.5 instructions per (row, query) in R^3
-template <int S, int D, int NQ, int NT>
+// MIN3 = 1: the screen of rrt_lanes.hip since round 2's second half -- a packed fused multiply-add covers the two ROWS of a
+// register pair for one query (the query's coordinate is the broadcast half, op_sel on the second operand) and one
+// v_min3_f32 folds both rows into the query's running minimum: D/2 + 1/2 = 2.0 instructions per (row, query) in R^3
+template <int S, int D, int NQ, int NT, int MIN3 = 0>
 __global__ __launch_bounds__(NT) void dot_kernel(const float* pts, uint64_t* cyc, uint32_t* sink, int iters) {
     static_assert(S % 2 == 0, "rows are held two per register pair");
     extern __shared__ char pad[];
@@ -243,6 +250,28 @@ __global__ __launch_bounds__(NT) void dot_kernel(const float* pts, uint64_t* cyc
         for (int b = 0; b < NQ; ++b)
 #pragma unroll
             for (int k = 0; k < D; ++k) q[b / 2][k][b % 2] = bits_f32(uni(f32_bits(qring[(it * NQ + b) & 63][k])));
+        if (MIN3) {
+#pragma unroll
+            for (int sp = 0; sp < S / 2; ++sp) {
+#pragma unroll
+                for (int b0 = 0; b0 < NQ; b0 += 4) {   // four queries' chains side by side
+                    f32x2 acc[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[t] = tcc[sp];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int b = b0 + t;
+                            const f32x2 qq = (b & 1) ? __builtin_shufflevector(q[b / 2][k], q[b / 2][k], 1, 1) : __builtin_shufflevector(q[b / 2][k], q[b / 2][k], 0, 0);
+                            acc[t] = __builtin_elementwise_fma(tr[k][sp], qq, acc[t]);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) asm("v_min3_f32 %0, %0, %1, %2" : "+v"(b1[b0 + t]) : "v"(acc[t][0]), "v"(acc[t][1]));
+                }
+            }
+        } else
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             f32x2 acc[NQ / 2];
@@ -345,6 +374,7 @@ int main() {
     RUN_OP(op32_kernel, FMA_F32, 0);
     RUN_OP(op32_kernel, MIN_F32, 0);
     RUN_OP(op32_kernel, MED3_F32, 0);
+    RUN_OP(op32_kernel, MIN3_F32, 0);
     RUN_OP(op_kernel, ADD_F64, 0);
     RUN_OP(op_kernel, FMA_F64, 1);
     printf(" },\n \"screen\": [\n");
@@ -384,6 +414,21 @@ int main() {
     } while (0)
     RUN_DOT(24, 3, 1); RUN_DOT(24, 3, 2); RUN_DOT(24, 3, 3); RUN_DOT(16, 3, 2);
     RUN_DOT(24, 2, 2); RUN_DOT(20, 4, 2); RUN_DOT(20, 5, 2); RUN_DOT(16, 6, 2);
+    printf("\n ],\n \"dot_screen_min3\": [\n");
+    first = true;
+#define RUN_DOT3(S_, D_, W_, NQ_)                                                                                  \
+    do {                                                                                                          \
+        Result r;                                                                                                 \
+        const int it = 3000;                                                                                      \
+        auto L = [&](int n) { hipLaunchKernelGGL((dot_kernel<S_, D_, NQ_, 256 * W_, 1>), dim3(n_cu), dim3(256 * W_), kLdsPad, 0, d_pts, d_cyc, d_sink, n); }; \
+        if (run(L, W_, it, (double)(S_) * (double)(NQ_), r, d_cyc, h_cyc)) return 1;                              \
+        const double rq_per_s_chip = (double)n_cu * 4 * W_ * (double)(S_) * (double)(NQ_) * it / (r.wall_ms * 1e-3); \
+        printf("%s  {\"rows\": %d, \"dim\": %d, \"waves_per_simd\": %d, \"queries_per_pass\": %d, \"ns_per_row_query_per_simd\": %.4f, \"wall_ms\": %.3f, " \
+               "\"row_queries_per_s_chip\": %.4e}", first ? "" : ",\n", S_, D_, W_, NQ_, r.ns_per_inst_simd, r.wall_ms, rq_per_s_chip); \
+        first = false;                                                                                            \
+    } while (0)
+    RUN_DOT3(24, 3, 1, 8); RUN_DOT3(24, 3, 2, 8); RUN_DOT3(24, 3, 3, 8); RUN_DOT3(16, 3, 2, 8); RUN_DOT3(20, 3, 2, 8);
+    RUN_DOT3(24, 2, 2, 8); RUN_DOT3(20, 4, 2, 8); RUN_DOT3(20, 5, 2, 8); RUN_DOT3(16, 6, 2, 8); RUN_DOT3(16, 6, 2, 4);
     printf("\n ]}\n");
     return 0;
 }
