@@ -202,6 +202,12 @@ def main():
     first_id, _ = sharding.problem_range(rank, P)
     gpu = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id,
                                device=local_rank, kernel=args.kernel)
+    # one tiny launch first: the first launch of a process pays for loading the code object (milliseconds, inside the
+    # HIP-event bracket of whatever runs first); the "grow" figure below is the second launch of the process
+    warm = scenarios.make_batch(sc, 4, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id, device=local_rank,
+                                kernel=args.kernel)
+    warm.solve(256)
+    warm.close()
     # untimed: grow every tree to 10,000 nodes (also the "grow" figure reported below)
     barrier()
     t0 = time.perf_counter()

@@ -78,7 +78,7 @@ struct DevParams {
     // binary32 screen of the streaming kernels (rrt_stream.hip, rrt_star.hip): fl32 shadow of the tree
     float* tree32;          // [P][dim][cap] fl32(tree), same layout; maintained by the kernels that insert
     uint32_t* shadow_state; // [P][2]: nodes whose shadow is valid; bits of the largest |fl32(coordinate)| among them
-    uint32_t dbg_flags;     // OXHIP_DEBUG_FLAGS (environment, read at batch creation): bit 0 = rrt_lanes.hip without its two-lane pass
+    uint32_t dbg_flags;     // OXHIP_DEBUG_FLAGS (environment, read at batch creation): bit 0 = rrt_lanes.hip without its two-lane pass; bit 1 = the diagnostic instantiation audits every accepted end state against the spheres (64 binary64 distances per query: off when timing with stamps)
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -90,19 +90,23 @@ struct Layout4 {
     static constexpr uint32_t kCapacity = kCommonNodes + (uint32_t)(S - C) * 384u;
     __device__ static __forceinline__ bool heavy(uint32_t wave) { return (wave & 3u) != 0; }
     __device__ static __forceinline__ uint32_t rows(uint32_t wave) { return heavy(wave) ? (uint32_t)S : (uint32_t)C; }
+    // The six heavy waves take a block's 1536 nodes in the order 3, 2, 7, 6, 1, 5: a partly filled last block costs its
+    // holders four more rows each, and waves 1 and 5 share their SIMD with the sampler wave (ChaCha12 + the draws: ~10
+    // instructions per query), so they come last; 3 / 2 first puts the first two partial holders on different SIMDs.
+    __device__ static __forceinline__ uint32_t hw_of_wave(uint32_t wave) { return (0x23500140u >> (4u * wave)) & 7u; }   // waves 1,2,3,5,6,7 -> 4,1,0,5,3,2
+    __device__ static __forceinline__ uint32_t wave_of_hw(uint32_t hw) { return (0x516723u >> (4u * hw)) & 7u; }        // 0..5 -> 3,2,7,6,1,5
     // first node of block `blk` of scanner thread `th` (kNoNode when that wave does not hold the block)
     __device__ static __forceinline__ uint32_t block_base(uint32_t th, uint32_t blk) {
         if (blk < (uint32_t)(C / 4)) return blk * 2048u + th * 4u;
         const uint32_t wave = th >> 6;
         if (!heavy(wave)) return kNoNode;
-        const uint32_t hw = wave - 1u - (wave > 4u ? 1u : 0u);   // waves 1,2,3,5,6,7 -> 0..5
-        return kCommonNodes + (blk - (uint32_t)(C / 4)) * 1536u + (hw * 64u + (th & 63u)) * 4u;
+        return kCommonNodes + (blk - (uint32_t)(C / 4)) * 1536u + (hw_of_wave(wave) * 64u + (th & 63u)) * 4u;
     }
     __device__ static __forceinline__ void locate(uint32_t i, uint32_t& thread, uint32_t& row) {
         if (i < kCommonNodes) { thread = (i & 2047u) >> 2; row = (i >> 11) * 4u + (i & 3u); return; }
         const uint32_t r = i - kCommonNodes, blk = r / 1536u, c = r % 1536u, ht = c >> 2, hw = ht >> 6;
         row = (uint32_t)C + blk * 4u + (c & 3u);
-        thread = (hw + 1u + (hw >= 3u ? 1u : 0u)) * 64u + (ht & 63u);
+        thread = wave_of_hw(hw) * 64u + (ht & 63u);
     }
     // rows of `wave` that may hold a node when the tree has n nodes (a multiple of four: whole blocks)
     __device__ static __forceinline__ uint32_t rows_in_use(uint32_t wave, uint32_t n) {
@@ -112,8 +116,7 @@ struct Layout4 {
         }
         if (!heavy(wave)) return (uint32_t)C;
         const uint32_t r = n - kCommonNodes, full = r / 1536u, rem = r % 1536u;
-        const uint32_t hw = wave - 1u - (wave > 4u ? 1u : 0u);
-        return (uint32_t)C + 4u * full + (rem > hw * 256u ? 4u : 0u);
+        return (uint32_t)C + 4u * full + (rem > hw_of_wave(wave) * 256u ? 4u : 0u);
     }
 };
 
@@ -446,14 +449,18 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             // per query ONE ballot: which lanes' smallest s' are within 2.5 E of the wave's?  The lane that holds the minimum is
             // always among them.  Exactly one: that lane, proven.  Exactly two: both are named (bits 0..8, bits 16..21 + bit 30) and
             // the resolver looks at both lanes' nodes, in whichever order.  More: not proven (bit 31), the resolver's whole-tree path.
-            uint32_t thv = 0;
+            uint64_t nearm[kPassQ];   // (all the ballots first: eight independent compare results instead of a chain through vcc)
 #pragma unroll
             for (int b = 0; b < kPassQ; ++b) {
                 const float thr = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(uthr), 8 * b));
-                const uint64_t nearm = __ballot(!(b1[b] > thr));   // (minimum +inf -- the wave holds no node yet -- : every lane)
-                const int nnear = __popcll(nearm);
-                const uint32_t wl = nearm ? (uint32_t)(__ffsll((unsigned long long)nearm) - 1) : 0u;
-                const uint64_t otherm = nearm & (nearm - 1ull);
+                nearm[b] = __ballot(!(b1[b] > thr));   // (minimum +inf -- the wave holds no node yet -- : every lane)
+            }
+            uint32_t thv = 0;
+#pragma unroll
+            for (int b = 0; b < kPassQ; ++b) {
+                const int nnear = __popcll(nearm[b]);
+                const uint32_t wl = nearm[b] ? (uint32_t)(__ffsll((unsigned long long)nearm[b]) - 1) : 0u;
+                const uint64_t otherm = nearm[b] & (nearm[b] - 1ull);
                 const uint32_t ol = (nnear == 2) ? (0x40000000u | ((uint32_t)(__ffsll((unsigned long long)otherm) - 1) << 16)) : 0u;
                 const uint32_t t = (wave * 64u + wl) | (nnear != 1 ? 0x80000000u : 0u) | ol;
                 asm("v_writelane_b32 %0, %1, %2" : "+v"(thv) : "s"(t), "n"(8 * b));   // lane 8b <- the wave-uniform record
@@ -481,6 +488,10 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
         for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
         __syncthreads();  // the launch's second barrier (see the scanners)
+        // while a tree grows everybody downstream waits for this wave: never queue behind the two scanner waves of this SIMD.
+        // (Not in the steady measurement: ChaCha12 and the draws are ~10 instructions per query, and at top priority they
+        // slowed the two scanners here -- the waves the other six then wait for: 953 -> 900 M it/s.)
+        if (!p.freeze) __builtin_amdgcn_s_setprio(3);
         RngWindow rng;
         rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st0.draws);
         uint32_t js = 0;
@@ -986,7 +997,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
         }
         OXHIP_PHASE(4);   // motion check
-        if (STAMP && p.dbg) {   // audit (diagnostic instantiation only): an accepted motion whose end state lies inside one of the first 64 spheres
+        if (STAMP && p.dbg && (p.dbg_flags & 2u) != 0) {   // audit (diagnostic instantiation with OXHIP_DEBUG_FLAGS bit 1): an accepted motion whose end state lies inside one of the first 64 spheres
             bool inval = false;
             for (uint32_t o = 0; o < ns64; ++o) {
                 double c[D];
@@ -1244,7 +1255,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid1)) != 0 || extras)
                     ok1 = motion_lanes<DIM>(p, lane, q_near1, qn1, oc, othr, ofilt, ns64);
             }
-            if (STAMP && p.dbg) {   // the same audit for the one-query path
+            if (STAMP && p.dbg && (p.dbg_flags & 2u) != 0) {   // the same audit for the one-query path
                 const bool inval1 = lane < ns64 && !(dist2<D>(oc, qn1, DIM) > othr);
                 if (ok1 && __ballot(inval1) != 0 && lane == 0) {
                     atomicAdd((unsigned long long*)&p.dbg[50], 1ull);

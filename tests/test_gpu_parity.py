@@ -327,7 +327,7 @@ def test_fuzz_seed203_r6_case(kernel, mode, monkeypatch):
     if no_pair:
         if kernel != capi.KERNEL_LANES:
             pytest.skip("the switch concerns the lane-per-query kernel only")
-        monkeypatch.setenv("OXHIP_DEBUG_FLAGS", "1")
+        monkeypatch.setenv("OXHIP_DEBUG_FLAGS", "3" if stamped else "1")   # bit 1: the diagnostic build's end-state audit
     dim = d["dim"]
     bounds = [(d["lo"], d["hi"])] * dim
     gpu = capi.RRTBatch(dim, bounds, d["md"], d["gb"], d["nprob"], d["max_nodes"], d["frac"], d["stop"], d["seed"], d["pid0"], 0, kernel)
