@@ -499,6 +499,7 @@ struct orc_rrts {
     double* cost;          /* Node::cost (rrt_star.rs:26), parallel to a->tree */
     uint32_t cap_cost;
     double search_radius;  /* rrt_star.rs:45 */
+    uint64_t wire;         /* W: the wiring polynomial of the build-defined checksum (see orc_rrts_solve) */
 };
 
 orc_rrts* orc_rrts_new(uint32_t dim, const double* bounds, double max_distance, double goal_bias, double search_radius,
@@ -534,6 +535,7 @@ static void rrts_push_cost(orc_rrts* r, double c) {
 /* rrt_star.rs:148-168: tree = [Node{start, None, 0.0}] */
 int orc_rrts_setup(orc_rrts* r, const double* start, const double* goal_centre, double goal_radius) {
     orc_rrt_setup(r->a, start, goal_centre, goal_radius);
+    r->wire = 0;
     rrts_push_cost(r, 0.0);
     return ORC_SOLVED;
 }
@@ -576,15 +578,25 @@ int orc_rrts_solve(orc_rrts* r, uint64_t max_iterations, double timeout_s) {
         }
         /* 5. check_motion(q_near, q_new) (:212-214) */
         int ok = check_motion(a, q_near, q_new);
-        uint64_t h = fnv_mix(a->checksum, (uint64_t)nearest);
-        for (uint32_t k = 0; k < dim; ++k) {
-            uint64_t b;
-            memcpy(&b, &q_new[k], sizeof b);
-            h = fnv_mix(h, b);
+        /* Build-defined checksum = H + W (mod 2^64).  H: RRT's iteration polynomial, H <- H P + g with g the FNV-1a fold of
+           (nearest, bits of q_new, verdict) -- the geometry of the run, which does not depend on any cost.  W: the wiring
+           polynomial, W <- W P + w per inserted node with w the fold of (chosen parent, bits of its cost, number and index
+           sum of the rewired neighbours).  Two chains, so that the geometry and the wiring can be computed by different
+           kernels; a single wrong parent, cost or rewire still changes the sum. */
+        uint64_t H = a->checksum - r->wire;
+        {
+            uint64_t g = fnv_mix(0xCBF29CE484222325ull, (uint64_t)nearest);
+            for (uint32_t k = 0; k < dim; ++k) {
+                uint64_t b;
+                memcpy(&b, &q_new[k], sizeof b);
+                g = fnv_mix(g, b);
+            }
+            g = fnv_mix(g, (uint64_t)ok);
+            H = H * 0x100000001B3ull + g;
         }
-        h = fnv_mix(h, (uint64_t)ok);
+        a->checksum = H + r->wire;
         a->iterations++;
-        if (!ok) { a->checksum = h; free(q_new); free(q_rand); continue; }
+        if (!ok) { free(q_new); free(q_rand); continue; }
         a->accepted++;
         /* find_neighbours (:121-131): distance(node.state, tree[i].state) < search_radius, ascending i */
         uint32_t n_nb = 0;
@@ -618,14 +630,15 @@ int orc_rrts_solve(orc_rrts* r, uint64_t max_iterations, double timeout_s) {
                 rew_sum += nb;
             }
         }
-        h = fnv_mix(h, (uint64_t)best_parent);
         {
-            uint64_t b;
+            uint64_t w = fnv_mix(0xCBF29CE484222325ull, (uint64_t)best_parent), b;
             memcpy(&b, &min_cost, sizeof b);
-            h = fnv_mix(h, b);
+            w = fnv_mix(w, b);
+            w = fnv_mix(w, rew_cnt);
+            w = fnv_mix(w, rew_sum);
+            r->wire = r->wire * 0x100000001B3ull + w;
+            a->checksum = H + r->wire;
         }
-        h = fnv_mix(h, rew_cnt);
-        a->checksum = fnv_mix(h, rew_sum);
         /* 9. goal (:285-288) */
         int hit = 0;
         if (goal_is_satisfied(a, q_new)) {

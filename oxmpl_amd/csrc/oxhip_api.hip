@@ -41,6 +41,12 @@ struct oxhip_rrt_batch {
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
+    // RRT*: W of the checksum; the decoupled design's buffers (rrt_star_wire.hip)
+    DevBuf<uint64_t> wire_chk;
+    DevBuf<uint32_t> wired, nbr_cnt, nbr_off, nbr_take;
+    DevBuf<double> d_near, sph_r;
+    DevBuf<StarEntry> pool;
+    bool star_wired = false;        // RRT*: geometry by rrt_lanes.hip + the wiring kernels (else rrt_star.hip)
     DevBuf<float> tree32;           // stream / RRT* kernels: fl32 shadow of the tree
     DevBuf<uint32_t> shadow_state;  // [P][2]
     DevBuf<uint32_t> nb_idx;
@@ -103,8 +109,13 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_BAD_ARG, "max_distance must be finite and > 0");
     if (cfg->kernel > OXHIP_KERNEL_LANES) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
     if (cfg->planner > OXHIP_PLANNER_RRT_STAR) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
-    if (cfg->planner != OXHIP_PLANNER_RRT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
-        return fail(OXHIP_ERR_BAD_ARG, "RRTConnect / RRT* run on the stream kernel only");
+    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
+        return fail(OXHIP_ERR_BAD_ARG, "RRTConnect runs on the stream kernel only");
+    // RRT*: KERNEL_STREAM = rrt_star.hip (one workgroup per problem, everything in one kernel); KERNEL_LANES = the decoupled
+    // design (geometry by rrt_lanes.hip, then the wiring kernels of rrt_star_wire.hip); KERNEL_AUTO = the latter where it exists
+    if (cfg->planner == OXHIP_PLANNER_RRT_STAR && cfg->kernel != OXHIP_KERNEL_AUTO && cfg->kernel != OXHIP_KERNEL_STREAM &&
+        cfg->kernel != OXHIP_KERNEL_LANES)
+        return fail(OXHIP_ERR_BAD_ARG, "RRT* runs on the stream kernel or on the lane-per-query kernel + wiring kernels");
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR && std::isnan(cfg->search_radius))
         return fail(OXHIP_ERR_BAD_ARG, "search_radius is NaN");
     double fraction = cfg->lvs_fraction, res = 0.0;
@@ -177,9 +188,32 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         chk(b->parent_b.alloc((size_t)P * cap));
     }
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR) {
+        const bool can_wire = star_wire_supported(dim) && lanes_supported(dim, cap);
+        b->star_wired = cfg->kernel == OXHIP_KERNEL_LANES || (cfg->kernel == OXHIP_KERNEL_AUTO && can_wire);
+        if (b->star_wired && !can_wire) {
+            oxhip_rrt_batch_destroy(b);
+            return fail(OXHIP_ERR_BAD_ARG, "decoupled RRT*: the lane-per-query kernel does not support this (dim, max_nodes)");
+        }
         chk(b->cost.alloc((size_t)P * cap));
-        chk(b->nb_idx.alloc((size_t)P * cap));
-        chk(b->nb_dist.alloc((size_t)P * cap));
+        chk(b->wire_chk.alloc(P));
+        if (b->star_wired) {
+            // neighbour lists: a pool segment per problem; a round wires the longest prefix of a problem's pending nodes whose
+            // lists fit (mean list length at radius 1 in configs[1]'s world: ~40), so the size bounds memory, not the result
+            uint64_t share = 64ull * cap;
+            const uint64_t budget_entries = (24ull << 30) / sizeof(StarEntry) / P;
+            if (share > budget_entries) share = budget_entries;
+            if (share < cap) share = cap;
+            dp.pool_share = (uint32_t)share;
+            chk(b->pool.alloc((size_t)P * share));
+            chk(b->wired.alloc(P));
+            chk(b->nbr_take.alloc(P));
+            chk(b->nbr_cnt.alloc((size_t)P * cap));
+            chk(b->nbr_off.alloc((size_t)P * cap));
+            chk(b->d_near.alloc((size_t)P * cap));
+        } else {
+            chk(b->nb_idx.alloc((size_t)P * cap));
+            chk(b->nb_dist.alloc((size_t)P * cap));
+        }
     }
     chk(b->state.alloc(P));
     chk(b->goal_c.alloc((size_t)P * dim));
@@ -192,10 +226,12 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.tree = b->tree.p; dp.parent = b->parent.p; dp.skip = b->skip.p; dp.state = b->state.p;
     dp.tree_b = b->tree_b.p; dp.parent_b = b->parent_b.p;
     dp.cost = b->cost.p; dp.nb_idx = b->nb_idx.p; dp.nb_dist = b->nb_dist.p;
+    dp.wire_chk = b->wire_chk.p; dp.wired = b->wired.p; dp.nbr_cnt = b->nbr_cnt.p; dp.nbr_off = b->nbr_off.p;
+    dp.nbr_take = b->nbr_take.p; dp.d_near = b->d_near.p; dp.pool = b->pool.p;
     dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p;
 
     uint32_t kind = cfg->kernel;
-    if (cfg->planner != OXHIP_PLANNER_RRT) kind = OXHIP_KERNEL_STREAM;
+    if (cfg->planner != OXHIP_PLANNER_RRT) kind = b->star_wired ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO)
         kind = lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES
              : resident32_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT_F32
@@ -218,7 +254,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     }
     b->kernel_kind = kind;
     b->last_kind = kind;
-    if ((cfg->planner == OXHIP_PLANNER_RRT && kind == OXHIP_KERNEL_STREAM) || cfg->planner == OXHIP_PLANNER_RRT_STAR) {
+    if ((cfg->planner == OXHIP_PLANNER_RRT && kind == OXHIP_KERNEL_STREAM) || (cfg->planner == OXHIP_PLANNER_RRT_STAR && !b->star_wired)) {
         // the streaming kernels screen their scans over an fl32 shadow of the tree, which they maintain themselves
         hipError_t e2 = b->tree32.alloc((size_t)P * dim * cap);
         if (e2 == hipSuccess) e2 = b->shadow_state.alloc((size_t)P * 2);
@@ -347,8 +383,15 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
         HIP_TRY(hipMemcpy2DAsync(b->parent_b.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
                                  sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
     }
-    if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR)   // start node: cost 0.0 (rrt_star.rs:163-167)
+    if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) {   // start node: cost 0.0 (rrt_star.rs:163-167)
         HIP_TRY(hipMemsetAsync(b->cost.p, 0, (size_t)P * cap * sizeof(double), b->stream));
+        HIP_TRY(hipMemsetAsync(b->wire_chk.p, 0, (size_t)P * sizeof(uint64_t), b->stream));
+        if (b->star_wired) {
+            std::vector<uint32_t> one(P, 1u);   // the start node needs no wiring
+            HIP_TRY(hipMemcpyAsync(b->wired.p, one.data(), (size_t)P * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->is_setup = true;
     return OXHIP_OK;
@@ -377,6 +420,11 @@ static int32_t refresh_filter(oxhip_rrt_batch* b) {
     int32_t st = upload(b->sph_filt, f, b->stream);
     if (st != OXHIP_OK) return st;
     b->dp.sph_filt = b->sph_filt.p;
+    if (b->star_wired) {   // motion_seq.hpp filters motions of any length: it takes the radii as given and this absolute margin
+        if ((st = upload(b->sph_r, b->sph_radii, b->stream)) != OXHIP_OK) return st;
+        b->dp.sph_r = b->sph_r.p;
+        b->dp.filt_abs = 1e-9 * maxabs;
+    }
     b->filt_dirty = false;
     return OXHIP_OK;
 }
@@ -444,6 +492,38 @@ static int32_t read_states(oxhip_rrt_batch* b, std::vector<ProblemState>& states
     return OXHIP_OK;
 }
 
+// Decoupled RRT*: parents and costs of the nodes the RRT kernel just inserted (rrt_star_wire.hip).  A round wires, per
+// problem, the longest prefix of its pending nodes whose neighbour lists fit the problem's pool segment; usually one round.
+static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
+    const uint32_t P = b->cfg.n_problems;
+    std::vector<ProblemState> states;
+    std::vector<uint32_t> wired(P), take(P);
+    for (;;) {
+        int32_t st = read_states(b, states);
+        if (st != OXHIP_OK) return st;
+        HIP_TRY(hipMemcpyAsync(wired.data(), b->wired.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        uint32_t max_pending = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t pend = states[p].n_nodes > wired[p] ? states[p].n_nodes - wired[p] : 0u;
+            max_pending = pend > max_pending ? pend : max_pending;
+        }
+        if (max_pending == 0) return OXHIP_OK;
+        launch_star_count(b->dp, max_pending, b->stream);
+        launch_star_scan(b->dp, b->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(take.data(), b->nbr_take.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        uint32_t max_take = 0;
+        for (uint32_t p = 0; p < P; ++p) max_take = take[p] > max_take ? take[p] : max_take;
+        if (max_take == 0) return fail(OXHIP_ERR_HIP, "RRT* wiring: no node fits the neighbour pool");   // (a list is at most cap <= pool_share long)
+        launch_star_fill(b->dp, max_take, b->stream);
+        launch_star_edges(b->dp, max_take, b->stream);
+        launch_star_wire(b->dp, b->stream);
+        HIP_TRY(hipGetLastError());
+    }
+}
+
 int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, double timeout_s, uint32_t freeze,
                               int32_t* status_out) {
     if (!b) return fail(OXHIP_ERR_BAD_ARG, "null batch");
@@ -478,6 +558,12 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
         if (b->cfg.space == OXHIP_SPACE_SE2) launch_rrt_connect_se2(b->dp, b->stream);
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
+        else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR && b->star_wired) {
+            // geometry: exactly RRT's loop on the same stream (rrt_star_wire.hip's header); then wire the new nodes
+            launch_rrt_lanes(b->dp, b->stream);
+            HIP_TRY(hipGetLastError());
+            if ((st = wire_new_nodes(b)) != OXHIP_OK) return st;
+        }
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) launch_rrt_star(b->dp, b->stream);
         else if (kind == OXHIP_KERNEL_PRUNED) launch_rrt_pruned(b->dp, b->stream);
         else if (kind == OXHIP_KERNEL_LANES) launch_rrt_lanes(b->dp, b->stream);
@@ -527,6 +613,12 @@ int32_t oxhip_rrt_batch_get_counts(oxhip_rrt_batch* b, uint64_t* iterations, uin
     if (st != OXHIP_OK) return st;
     std::vector<ProblemState> states;
     if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) {   // reported checksum = H (iterations) + W (wiring), DESIGN.md section 10
+        std::vector<uint64_t> w(b->cfg.n_problems);
+        HIP_TRY(hipMemcpyAsync(w.data(), b->wire_chk.p, w.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        for (uint32_t p = 0; p < b->cfg.n_problems; ++p) states[p].checksum += w[p];
+    }
     for (uint32_t p = 0; p < b->cfg.n_problems; ++p) {
         if (iterations) iterations[p] = states[p].iterations;
         if (nodes) nodes[p] = states[p].n_nodes;

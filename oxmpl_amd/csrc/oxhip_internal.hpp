@@ -36,6 +36,14 @@ void launch_se2_check_motion(const DevParams& p, const double* from, const doubl
 // rrt_star.hip: RRT* (rrt_star.rs), one 256-thread workgroup per problem
 void launch_rrt_star(const DevParams& p, hipStream_t stream);
 
+// rrt_star_wire.hip: the wiring stages of the decoupled RRT* (the geometry comes from launch_rrt_lanes)
+bool star_wire_supported(uint32_t dim);
+void launch_star_count(const DevParams& p, uint32_t max_pending, hipStream_t stream);   // nbr_cnt of the nodes [wired, n)
+void launch_star_scan(const DevParams& p, hipStream_t stream);                          // nbr_off, nbr_take
+void launch_star_fill(const DevParams& p, uint32_t max_take, hipStream_t stream);       // the lists of [wired, wired + take)
+void launch_star_edges(const DevParams& p, uint32_t max_take, hipStream_t stream);      // distances, both motions' validity
+void launch_star_wire(const DevParams& p, hipStream_t stream);                          // choose parent / rewire, node by node
+
 // rrt_resident.hip
 // true when a register-resident instantiation exists for (dim, cap)
 bool resident_supported(uint32_t dim, uint32_t cap);

@@ -37,6 +37,13 @@ struct ProblemState {
     uint32_t pad;
 };
 
+// one neighbour of one node (rrt_star_wire.hip): written as (j, 0, d2) by the pair search, completed by the edge kernel
+struct StarEntry {
+    uint32_t j;        // the neighbour's index (< the node's own)
+    uint32_t flags;    // bit 0: check_motion(neighbour, node) holds; bit 1: check_motion(node, neighbour) holds
+    double d;          // distance(node, neighbour)  (the pair search leaves the squared distance here)
+};
+
 // kernel arguments (by value)
 struct DevParams {
     uint32_t dim, n_problems, cap, max_nodes;
@@ -72,6 +79,15 @@ struct DevParams {
     uint32_t* nb_idx;       // [P][cap] scratch: find_neighbours' result of the current iteration
     double* nb_dist;        // [P][cap] scratch: distance(q_new, neighbour)
     double thr_search;      // largest d2 with sqrt(d2) < search_radius (strict, rrt_star.rs:125)
+    uint64_t* wire_chk;     // [P] W, the wiring polynomial of RRT*'s checksum (ProblemState::checksum holds H; reported: H + W)
+    // RRT*, decoupled design (rrt_star_wire.hip): geometry by the RRT kernel, then neighbour lists, edge validity, wiring
+    uint32_t* wired;        // [P] nodes whose parent and cost are final (the wiring cursor; node 0 is wired by setup)
+    uint32_t* nbr_cnt;      // [P][cap] |find_neighbours(node)| among the nodes before it
+    uint32_t* nbr_off;      // [P][cap] where the node's list starts in the problem's pool segment (this round)
+    uint32_t* nbr_take;     // [P] nodes wired this round: the longest prefix of the pending nodes whose lists fit the segment
+    double* d_near;         // [P][cap] distance(node, its nearest node)
+    struct StarEntry* pool; // [P][pool_share] neighbour lists, ascending index within a list
+    uint32_t pool_share;
     // PRM only (prm_kernels.hip): the midpoint filter's inputs for motions of any length
     const double* sph_r;    // [n_spheres] radii as given
     double filt_abs;        // 1e-9 * largest coordinate magnitude in play (absolute rounding margin)

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kStarThreads, DIM ? 4 : 1) void rrt_star_kernel(Dev
     rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
 
     uint32_t n = st.n_nodes;
+    uint64_t wire = p.wire_chk[prob];
     // binary32 shadow of the tree: both scans of an iteration screen over it (rrt_device.hpp) and decide in binary64
     float* tree32 = p.tree32 + (size_t)prob * p.dim * cap;
     const ScreenMargins mg = screen_margins(shadow_sync<D>(p, dim, prob, tree, tree32, cap, n, goal_c, &sh.shadow_word, tid, kStarThreads), dim);
@@ -162,12 +163,11 @@ __global__ __launch_bounds__(kStarThreads, DIM ? 4 : 1) void rrt_star_kernel(Dev
         // 5. check_motion(q_near, q_new) (rrt_star.rs:212-214)
         const bool bad = motion_invalid_wg<D>(p, dim, q_near, q_new, tid, kStarThreads);
         const bool ok = !__syncthreads_or(bad ? 1 : 0);
-        uint64_t h = fnv_mix(st.checksum, (uint64_t)nearest);
-#pragma unroll
-        for (int k = 0; k < D; ++k) if (k < dim) h = fnv_mix(h, (uint64_t)__double_as_longlong(q_new[k]));
-        h = fnv_mix(h, ok ? 1ull : 0ull);
+        // checksum = H + W: H, the iteration polynomial of RRT's digests, lives in the problem state;
+        // W, the wiring polynomial, in wire_chk
+        st.checksum = chk_push(st.checksum, iter_digest<D>(nearest, q_new, dim, ok));
         st.iterations++;
-        if (!ok) { st.checksum = h; continue; }
+        if (!ok) continue;
         st.accepted++;
 
         // 6a. cost via the nearest node: cost(temp_node, q_near_node) = q_near.cost + distance(q_new, q_near) (:104-113, :228)
@@ -278,10 +278,13 @@ __global__ __launch_bounds__(kStarThreads, DIM ? 4 : 1) void rrt_star_kernel(Dev
             atomicAdd(&sh.rew_sum, my_sum);
         }
         __syncthreads();   // the new node, the rewired parents / costs and the counters are visible
-        h = fnv_mix(h, (uint64_t)best_parent);
-        h = fnv_mix(h, (uint64_t)__double_as_longlong(min_cost));
-        h = fnv_mix(h, (uint64_t)sh.rew_cnt);
-        st.checksum = fnv_mix(h, (uint64_t)sh.rew_sum);
+        {
+            uint64_t w = fnv_mix(kFnvBasis, (uint64_t)best_parent);
+            w = fnv_mix(w, (uint64_t)__double_as_longlong(min_cost));
+            w = fnv_mix(w, (uint64_t)sh.rew_cnt);
+            w = fnv_mix(w, (uint64_t)sh.rew_sum);
+            wire = wire * kFnvPrime + w;
+        }
 
         // 9. goal test (rrt_star.rs:285-288)
         if (dist2<D>(q_new, goal_c, dim) <= goal_thr) {
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(kStarThreads, DIM ? 4 : 1) void rrt_star_kernel(Dev
         st.draws = rng.pos;
         st.stop_reason = stop;
         p.state[prob] = st;
+        p.wire_chk[prob] = wire;
         p.shadow_state[2 * (size_t)prob] = n;
         p.shadow_state[2 * (size_t)prob + 1] = sh.shadow_word;
     }

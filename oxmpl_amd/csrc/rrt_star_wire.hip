@@ -1,0 +1,257 @@
+// rrt_star_wire.hip -- the wiring stages of the decoupled RRT* (oxmpl/src/geometric/planners/rrt_star.rs:170-289).
+//
+// What makes RRT* expensive on a GPU is find_neighbours (:121-131): a second scan of the whole tree per accepted iteration,
+// issued only after that iteration's nearest-neighbour query has been answered -- a chain of dependent memory round trips.
+// But the GEOMETRY of an RRT* run does not depend on any cost:
+//   * q_rand comes from the RNG stream, nearest from the node positions, q_new from both (:178-209);
+//   * the node is inserted iff check_motion(q_near, q_new) holds (:212-214) -- the nearest node is always an admissible
+//     parent, choose-parent (:225-241) can only replace it -- and it is inserted AT q_new whatever its parent (:244-250);
+//   * the loop ends on goal.is_satisfied(q_new) (:285-288).
+// So the sequence of node positions (and of nearest indices, verdicts, the goal node, the RNG position) is exactly RRT's
+// (rrt.rs:170-225) on the same stream, and rrt_lanes.hip produces it at RRT speed.  What is left -- parents and costs --
+// is a function of the positions alone:
+//   1. star_pairs   N(i) = { j < i : distance(x_i, x_j) < search_radius }, ascending j: the tree as node i found it.
+//                   All pairs of all nodes at once (count, prefix sum, fill): throughput, not latency.
+//   2. star_edges   per neighbour pair: distance, check_motion(x_j, x_i) and check_motion(x_i, x_j) -- is_valid is pure, so
+//                   evaluating a motion the reference skipped (its cost test failed) changes nothing.
+//   3. star_wire    one wave per problem walks the nodes in insertion order: choose parent = the lexicographic minimum of
+//                   (cost via neighbour, index) among the neighbours with a valid motion and a cost below the nearest
+//                   node's (what the reference's ascending walk with its running minimum computes, :231-240); rewire: every
+//                   neighbour but the parent whose cost drops and whose motion is valid (:253-282; each decision depends on
+//                   that neighbour's own cost only).  Costs are read and written in order, so rewires of earlier nodes are
+//                   seen by later ones exactly as in the reference.
+// Everything that enters a result is binary64 in the reference's evaluation order.
+#include "oxhip_internal.hpp"
+#include "rrt_device.hpp"
+#include "motion_seq.hpp"
+
+namespace oxhip {
+
+constexpr int kPairThreads = 256;
+
+// ---- 1. neighbour lists.  A thread owns node i and walks j = 0 .. i-1; the 64 nodes of a wave are consecutive, j is
+// wave-uniform (x_j comes through the scalar cache).  FILL = false counts, FILL = true writes (j, 0, d2) at the node's offset.
+template <int DIM, bool FILL>
+__global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
+    const uint32_t prob = blockIdx.y;
+    const uint32_t n = p.state[prob].n_nodes;
+    const uint32_t w0 = p.wired[prob];
+    const uint32_t hi = FILL ? w0 + p.nbr_take[prob] : n;   // nodes [w0, hi)
+    const uint32_t wave_first = uni(w0 + blockIdx.x * kPairThreads + (threadIdx.x & ~63u));
+    if (wave_first >= hi) return;
+    const uint32_t i = w0 + blockIdx.x * kPairThreads + threadIdx.x;
+    const bool act = i < hi;
+    const size_t cap = p.cap;
+    const double* __restrict__ tree = p.tree + (size_t)prob * DIM * cap;
+    double x[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) x[k] = tree[(size_t)k * cap + (act ? i : w0)];
+    const uint32_t last = hi - 1u < wave_first + 63u ? hi - 1u : wave_first + 63u;   // the wave's largest node: j < last
+    const double thr = p.thr_search;
+    uint32_t cnt = 0;
+    StarEntry* __restrict__ out = nullptr;
+    if (FILL && act) out = p.pool + (size_t)prob * p.pool_share + p.nbr_off[(size_t)prob * cap + i];
+    uint32_t j = 0;
+    for (; j + 4 <= last; j += 4) {   // four wave-uniform nodes per trip
+        double d2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            double c[DIM];
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + j + t];
+            d2[t] = dist2<DIM>(x, c, DIM);   // distance(node.state, tree[j].state), rrt_star.rs:125
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (act && j + t < i && d2[t] <= thr) {
+                if (FILL) out[cnt] = StarEntry{j + (uint32_t)t, 0u, d2[t]};
+                ++cnt;
+            }
+        }
+    }
+    for (; j < last; ++j) {
+        double c[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + j];
+        const double d2 = dist2<DIM>(x, c, DIM);
+        if (act && j < i && d2 <= thr) {
+            if (FILL) out[cnt] = StarEntry{j, 0u, d2};
+            ++cnt;
+        }
+    }
+    if (!FILL && act) p.nbr_cnt[(size_t)prob * cap + i] = cnt;
+}
+
+// ---- exclusive prefix of the pending nodes' counts, and how many of them fit the problem's pool segment this round
+__global__ __launch_bounds__(256) void star_scan_kernel(DevParams p) {
+    const uint32_t prob = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = p.state[prob].n_nodes, w0 = p.wired[prob];
+    const uint32_t pending = n > w0 ? n - w0 : 0u;
+    __shared__ unsigned long long part[256];
+    __shared__ uint32_t first_over;
+    if (tid == 0) first_over = pending;
+    const size_t base = (size_t)prob * p.cap;
+    const uint32_t seg = (pending + 255u) / 256u;
+    const uint32_t a = tid * seg < pending ? tid * seg : pending;
+    const uint32_t b = a + seg < pending ? a + seg : pending;
+    unsigned long long s = 0;
+    for (uint32_t t = a; t < b; ++t) s += p.nbr_cnt[base + w0 + t];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {   // 256 partial sums: a serial pass is cheaper than it looks next to the kernels around it
+        unsigned long long run = 0;
+        for (int t = 0; t < 256; ++t) { const unsigned long long v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    unsigned long long run = part[tid];
+    for (uint32_t t = a; t < b; ++t) {
+        const uint32_t c = p.nbr_cnt[base + w0 + t];
+        if (run + c > (unsigned long long)p.pool_share) { atomicMin(&first_over, t); break; }   // (a list is at most cap <= pool_share long)
+        p.nbr_off[base + w0 + t] = (uint32_t)run;
+        run += c;
+    }
+    __syncthreads();
+    if (tid == 0) p.nbr_take[prob] = first_over;
+}
+
+// ---- 2. one wave per node: its neighbours' distances and the validity of both motions; the node's distance to its
+// nearest node (the parent the RRT kernel recorded)
+template <int DIM>
+__global__ __launch_bounds__(256) void star_edges_kernel(DevParams p) {
+    const uint32_t prob = blockIdx.y, lane = threadIdx.x & 63u;
+    const uint32_t w0 = p.wired[prob], take = p.nbr_take[prob];
+    const uint32_t t = uni(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (t >= take) return;
+    const uint32_t i = w0 + t;
+    const size_t cap = p.cap, base = (size_t)prob * cap;
+    const double* __restrict__ tree = p.tree + (size_t)prob * DIM * cap;
+    double x[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) x[k] = tree[(size_t)k * cap + i];
+    if (lane == 0) {
+        const uint32_t nearest = (uint32_t)p.parent[base + i];
+        double c[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + nearest];
+        p.d_near[base + i] = sqrt(dist2<DIM>(x, c, DIM));   // distance(q_new, q_near), rrt_star.rs:228
+    }
+    const uint32_t cnt = p.nbr_cnt[base + i];
+    StarEntry* list = p.pool + (size_t)prob * p.pool_share + p.nbr_off[base + i];
+    for (uint32_t e = lane; e < cnt; e += 64) {
+        StarEntry en = list[e];
+        double c[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + en.j];
+        uint32_t f = 0;
+        if (motion_valid_seq<DIM>(p, c, x)) f |= 1u;   // check_motion(neighbour, q_new), rrt_star.rs:235
+        if (motion_valid_seq<DIM>(p, x, c)) f |= 2u;   // check_motion(new, neighbour), rrt_star.rs:271
+        en.flags = f;
+        en.d = sqrt(en.d);
+        list[e] = en;
+    }
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64_shfl(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+// ---- 3. one wave per problem: rrt_star.rs:225-282 for the nodes [wired, wired + take) in insertion order
+__global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
+    const uint32_t prob = blockIdx.x, lane = threadIdx.x;
+    const uint32_t w0 = p.wired[prob], take = p.nbr_take[prob];
+    if (take == 0) return;
+    const size_t cap = p.cap, base = (size_t)prob * cap;
+    double* cost = p.cost + base;
+    int32_t* parent = p.parent + base;
+    const StarEntry* pool = p.pool + (size_t)prob * p.pool_share;
+    uint64_t W = p.wire_chk[prob];
+    for (uint32_t i = w0; i < w0 + take; ++i) {
+        const uint32_t cnt = uni(p.nbr_cnt[base + i]);
+        const StarEntry* list = pool + p.nbr_off[base + i];
+        const uint32_t nearest = uni((uint32_t)parent[i]);
+        // 6. choose parent: cost(temp_node, q_near_node) first (:228), then the neighbours in ascending index with the running minimum
+        const double c0 = unid(cost[nearest] + p.d_near[base + i]);
+        double best_c = c0;
+        uint32_t best_j = nearest;
+        for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
+            const bool has = e0 + lane < cnt;
+            const StarEntry en = list[has ? e0 + lane : 0u];
+            const double c = cost[en.j] + en.d;                          // cost(temp_node, neighbour), :104-113
+            const bool cand = has && (en.flags & 1u) != 0 && c < best_c;   // strict: an equal cost keeps the earlier choice
+            const double cm = wave_min_f64(cand ? c : __builtin_inf());
+            const uint64_t m = __ballot(cand && c == cm);
+            if (m != 0) {   // the trip's cheapest valid candidate, lowest index among equals (the list is ascending)
+                const int l = __ffsll((unsigned long long)m) - 1;
+                best_c = unid(cm);
+                best_j = (uint32_t)__builtin_amdgcn_readlane((int)en.j, l);
+            }
+        }
+        // 7. push: parent and cost of the new node (:244-250)
+        if (lane == 0) { parent[i] = (int32_t)best_j; cost[i] = best_c; }
+        // 8. rewire (:253-282)
+        uint64_t rew_cnt = 0, rew_sum = 0;
+        for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
+            const bool has = e0 + lane < cnt;
+            const StarEntry en = list[has ? e0 + lane : 0u];
+            const double c2 = best_c + en.d;                             // cost(neighbour, new_node), :265
+            const bool rw = has && en.j != best_j && c2 < cost[en.j] && (en.flags & 2u) != 0;
+            if (rw) { parent[en.j] = (int32_t)i; cost[en.j] = c2; }
+            rew_cnt += (uint64_t)__popcll(__ballot(rw));
+            rew_sum += wave_sum_u64_shfl(rw ? (uint64_t)en.j : 0ull);
+        }
+        uint64_t w = fnv_mix(kFnvBasis, (uint64_t)best_j);
+        w = fnv_mix(w, (uint64_t)__double_as_longlong(best_c));
+        w = fnv_mix(w, rew_cnt);
+        w = fnv_mix(w, rew_sum);
+        W = W * kFnvPrime + w;
+        // this wave's stores to cost / parent are complete before the next node reads them (same CU: a wait, no cache op)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+    if (lane == 0) {
+        p.wire_chk[prob] = W;
+        p.wired[prob] = w0 + take;
+    }
+}
+
+bool star_wire_supported(uint32_t dim) { return dim >= 2 && dim <= 6; }
+
+template <bool FILL>
+static void launch_pairs(const DevParams& p, uint32_t max_nodes, hipStream_t stream) {
+    if (max_nodes == 0) return;
+    dim3 grid((max_nodes + kPairThreads - 1) / kPairThreads, p.n_problems), block(kPairThreads);
+    switch (p.dim) {
+        case 2: hipLaunchKernelGGL((star_pairs_kernel<2, FILL>), grid, block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL((star_pairs_kernel<3, FILL>), grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL((star_pairs_kernel<4, FILL>), grid, block, 0, stream, p); break;
+        case 5: hipLaunchKernelGGL((star_pairs_kernel<5, FILL>), grid, block, 0, stream, p); break;
+        case 6: hipLaunchKernelGGL((star_pairs_kernel<6, FILL>), grid, block, 0, stream, p); break;
+        default: break;
+    }
+}
+void launch_star_count(const DevParams& p, uint32_t max_pending, hipStream_t stream) { launch_pairs<false>(p, max_pending, stream); }
+void launch_star_fill(const DevParams& p, uint32_t max_take, hipStream_t stream) { launch_pairs<true>(p, max_take, stream); }
+void launch_star_scan(const DevParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(star_scan_kernel, dim3(p.n_problems), dim3(256), 0, stream, p);
+}
+void launch_star_edges(const DevParams& p, uint32_t max_take, hipStream_t stream) {
+    if (max_take == 0) return;
+    dim3 grid((max_take + 3) / 4, p.n_problems), block(256);
+    switch (p.dim) {
+        case 2: hipLaunchKernelGGL(star_edges_kernel<2>, grid, block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(star_edges_kernel<3>, grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL(star_edges_kernel<4>, grid, block, 0, stream, p); break;
+        case 5: hipLaunchKernelGGL(star_edges_kernel<5>, grid, block, 0, stream, p); break;
+        case 6: hipLaunchKernelGGL(star_edges_kernel<6>, grid, block, 0, stream, p); break;
+        default: break;
+    }
+}
+void launch_star_wire(const DevParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL(star_wire_kernel, dim3(p.n_problems), dim3(64), 0, stream, p);
+}
+
+}  // namespace oxhip

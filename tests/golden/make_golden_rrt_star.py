@@ -39,7 +39,7 @@ def rrt_star_solve(dim, bounds, max_distance, goal_bias, search_radius, fraction
     tree[0] = start
     parents, cost = [-1], [0.0]
     n = 1
-    chk = 0xCBF29CE484222325
+    h_iter, w_wire = 0xCBF29CE484222325, 0       # checksum = H + W: iteration polynomial + wiring polynomial (oracle/rrt_oracle.c)
     iterations = accepted = rewires = 0
     goal_node = -1
     for _ in range(max_iterations):
@@ -56,10 +56,11 @@ def rrt_star_solve(dim, bounds, max_distance, goal_bias, search_radius, fraction
         q_near = [float(v) for v in tree[nearest]]
         q_new = interpolate(q_near, q_rand, max_distance / min_dist) if min_dist > max_distance else list(q_rand)
         ok = check_motion(field, bounds, fraction, q_near, q_new)
-        chk = ((chk ^ nearest) * FNV_P) & M64
+        g = ((0xCBF29CE484222325 ^ nearest) * FNV_P) & M64
         for v in q_new:
-            chk = ((chk ^ f64_bits(v)) * FNV_P) & M64
-        chk = ((chk ^ int(ok)) * FNV_P) & M64
+            g = ((g ^ f64_bits(v)) * FNV_P) & M64
+        g = ((g ^ int(ok)) * FNV_P) & M64
+        h_iter = (h_iter * FNV_P + g) & M64
         iterations += 1
         if not ok:
             continue
@@ -87,8 +88,10 @@ def rrt_star_solve(dim, bounds, max_distance, goal_bias, search_radius, fraction
                 rew_cnt += 1
                 rew_sum += i
         rewires += rew_cnt
+        w = 0xCBF29CE484222325
         for v in (best_parent, f64_bits(min_cost), rew_cnt, rew_sum):
-            chk = ((chk ^ v) * FNV_P) & M64
+            w = ((w ^ v) * FNV_P) & M64
+        w_wire = (w_wire * FNV_P + w) & M64
         if distance(q_new, goal_c) <= goal_r:
             if goal_node < 0:
                 goal_node = new_idx
@@ -101,6 +104,7 @@ def rrt_star_solve(dim, bounds, max_distance, goal_bias, search_radius, fraction
             path.append([float(v) for v in tree[i]])
             i = parents[i]
         path.reverse()
+    chk = (h_iter + w_wire) & M64
     return dict(n=n, iterations=iterations, accepted=accepted, rewires=rewires, checksum=chk, goal_node=goal_node,
                 states=tree[:n].copy(), parents=parents, cost=cost, path=path)
 

@@ -1,7 +1,8 @@
-"""GPU parity tests of RRT* (planner kind 2, rrt_star.hip) through the C ABI against the CPU oracle
-(orc_rrts_*) and the golden fixtures: node count, iteration count, per-iteration checksum (nearest, q_new,
-verdict, chosen parent, cost bits, rewired count and index sum), tree bits, parents after rewiring, costs, path.
-PARITY UNPINNED against oxmpl itself."""
+"""GPU parity tests of RRT* (planner kind 2) through the C ABI against the CPU oracle (orc_rrts_*) and the golden
+fixtures: node count, iteration count, checksum (iteration polynomial over nearest / q_new / verdict + wiring polynomial over
+chosen parent / cost bits / rewired count and index sum), tree bits, parents after rewiring, costs, path.
+Every test runs on both designs: "decoupled" (KERNEL_AUTO: geometry by rrt_lanes.hip, wiring by rrt_star_wire.hip) and
+"one_kernel" (KERNEL_STREAM: rrt_star.hip).  PARITY UNPINNED against oxmpl itself."""
 import json
 import os
 
@@ -16,6 +17,14 @@ from oxmpl_amd import capi  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DESIGN = {"kernel": capi.KERNEL_AUTO}
+
+
+@pytest.fixture(autouse=True, params=["decoupled", "one_kernel"])
+def star_design(request):
+    DESIGN["kernel"] = capi.KERNEL_AUTO if request.param == "decoupled" else capi.KERNEL_STREAM
+    yield request.param
+    DESIGN["kernel"] = capi.KERNEL_AUTO
 
 
 @pytest.fixture(scope="module")
@@ -37,7 +46,7 @@ def make_oracle(P, seed, pid, stop=True, max_nodes=None):
 
 def make_gpu(P, n_problems, seed, first_pid, stop=True, max_nodes=None):
     g = capi.RRTBatch(P["dim"], P["bounds"], P["max_distance"], P["goal_bias"], n_problems, max_nodes or P["max_nodes"],
-                      P["fraction"], stop, seed, first_pid, 0, capi.KERNEL_AUTO, capi.PLANNER_RRT_STAR, P["search_radius"])
+                      P["fraction"], stop, seed, first_pid, 0, DESIGN["kernel"], capi.PLANNER_RRT_STAR, P["search_radius"])
     if P["spheres"]:
         g.set_spheres(*params_spheres(P))
     if P["boxes"]:
@@ -141,7 +150,7 @@ def test_rrt_star_translated_and_scaled_spaces(star_golden, scale, offset):
     c, r = np.asarray(c) * scale + offset, np.asarray(r) * scale
     n_prob = 4
     g = capi.RRTBatch(P["dim"], P["bounds"], P["max_distance"], P["goal_bias"], n_prob, 2000, P["fraction"], False, 9, 300, 0,
-                      capi.KERNEL_AUTO, capi.PLANNER_RRT_STAR, P["search_radius"])
+                      DESIGN["kernel"], capi.PLANNER_RRT_STAR, P["search_radius"])
     g.set_spheres(c, r)
     g.setup(P["start"], P["goal_c"], P["goal_r"])
     g.solve(600)
