@@ -43,7 +43,7 @@ struct oxhip_rrt_batch {
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
     // RRT*: W of the checksum; the decoupled design's buffers (rrt_star_wire.hip)
     DevBuf<uint64_t> wire_chk;
-    DevBuf<uint32_t> wired, nbr_cnt, nbr_off, nbr_take;
+    DevBuf<uint32_t> wired, nbr_cnt, nbr_off, nbr_take, nbr_total;
     DevBuf<double> d_near, sph_r;
     DevBuf<StarEntry> pool;
     bool star_wired = false;        // RRT*: geometry by rrt_lanes.hip + the wiring kernels (else rrt_star.hip)
@@ -207,6 +207,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             chk(b->pool.alloc((size_t)P * share));
             chk(b->wired.alloc(P));
             chk(b->nbr_take.alloc(P));
+            chk(b->nbr_total.alloc(P));
             chk(b->nbr_cnt.alloc((size_t)P * cap));
             chk(b->nbr_off.alloc((size_t)P * cap));
             chk(b->d_near.alloc((size_t)P * cap));
@@ -227,7 +228,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.tree_b = b->tree_b.p; dp.parent_b = b->parent_b.p;
     dp.cost = b->cost.p; dp.nb_idx = b->nb_idx.p; dp.nb_dist = b->nb_dist.p;
     dp.wire_chk = b->wire_chk.p; dp.wired = b->wired.p; dp.nbr_cnt = b->nbr_cnt.p; dp.nbr_off = b->nbr_off.p;
-    dp.nbr_take = b->nbr_take.p; dp.d_near = b->d_near.p; dp.pool = b->pool.p;
+    dp.nbr_take = b->nbr_take.p; dp.nbr_total = b->nbr_total.p; dp.d_near = b->d_near.p; dp.pool = b->pool.p;
     dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p;
 
     uint32_t kind = cfg->kernel;
@@ -497,7 +498,7 @@ static int32_t read_states(oxhip_rrt_batch* b, std::vector<ProblemState>& states
 static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
     const uint32_t P = b->cfg.n_problems;
     std::vector<ProblemState> states;
-    std::vector<uint32_t> wired(P), take(P);
+    std::vector<uint32_t> wired(P), take(P), total(P);
     for (;;) {
         int32_t st = read_states(b, states);
         if (st != OXHIP_OK) return st;
@@ -513,12 +514,16 @@ static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
         launch_star_scan(b->dp, b->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(take.data(), b->nbr_take.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(total.data(), b->nbr_total.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
-        uint32_t max_take = 0;
-        for (uint32_t p = 0; p < P; ++p) max_take = take[p] > max_take ? take[p] : max_take;
+        uint32_t max_take = 0, max_total = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            max_take = take[p] > max_take ? take[p] : max_take;
+            max_total = total[p] > max_total ? total[p] : max_total;
+        }
         if (max_take == 0) return fail(OXHIP_ERR_HIP, "RRT* wiring: no node fits the neighbour pool");   // (a list is at most cap <= pool_share long)
         launch_star_fill(b->dp, max_take, b->stream);
-        launch_star_edges(b->dp, max_take, b->stream);
+        launch_star_edges(b->dp, max_total, b->stream);
         launch_star_wire(b->dp, b->stream);
         HIP_TRY(hipGetLastError());
     }

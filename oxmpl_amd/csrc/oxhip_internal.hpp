@@ -41,7 +41,7 @@ bool star_wire_supported(uint32_t dim);
 void launch_star_count(const DevParams& p, uint32_t max_pending, hipStream_t stream);   // nbr_cnt of the nodes [wired, n)
 void launch_star_scan(const DevParams& p, hipStream_t stream);                          // nbr_off, nbr_take
 void launch_star_fill(const DevParams& p, uint32_t max_take, hipStream_t stream);       // the lists of [wired, wired + take)
-void launch_star_edges(const DevParams& p, uint32_t max_take, hipStream_t stream);      // distances, both motions' validity
+void launch_star_edges(const DevParams& p, uint32_t max_total, hipStream_t stream);     // per pair: distance, both motions' validity
 void launch_star_wire(const DevParams& p, hipStream_t stream);                          // choose parent / rewire, node by node
 
 // rrt_resident.hip

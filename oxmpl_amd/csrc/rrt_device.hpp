@@ -85,6 +85,7 @@ struct DevParams {
     uint32_t* nbr_cnt;      // [P][cap] |find_neighbours(node)| among the nodes before it
     uint32_t* nbr_off;      // [P][cap] where the node's list starts in the problem's pool segment (this round)
     uint32_t* nbr_take;     // [P] nodes wired this round: the longest prefix of the pending nodes whose lists fit the segment
+    uint32_t* nbr_total;    // [P] neighbour pairs of those nodes (the used part of the pool segment)
     double* d_near;         // [P][cap] distance(node, its nearest node)
     struct StarEntry* pool; // [P][pool_share] neighbour lists, ascending index within a list
     uint32_t pool_share;

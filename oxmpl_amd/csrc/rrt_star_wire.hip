@@ -30,7 +30,8 @@ namespace oxhip {
 constexpr int kPairThreads = 256;
 
 // ---- 1. neighbour lists.  A thread owns node i and walks j = 0 .. i-1; the 64 nodes of a wave are consecutive, j is
-// wave-uniform (x_j comes through the scalar cache).  FILL = false counts, FILL = true writes (j, 0, d2) at the node's offset.
+// wave-uniform (x_j comes through the scalar cache).  FILL = false counts, FILL = true writes (j, i, d2) at the node's offset
+// (the owner i rides in the flags word until the edge kernel replaces it) and the node's distance to its nearest node.
 template <int DIM, bool FILL>
 __global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
     const uint32_t prob = blockIdx.y;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (act && j + t < i && d2[t] <= thr) {
-                if (FILL) out[cnt] = StarEntry{j + (uint32_t)t, 0u, d2[t]};
+                if (FILL) out[cnt] = StarEntry{j + (uint32_t)t, i, d2[t]};
                 ++cnt;
             }
         }
@@ -75,11 +76,18 @@ __global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
         for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + j];
         const double d2 = dist2<DIM>(x, c, DIM);
         if (act && j < i && d2 <= thr) {
-            if (FILL) out[cnt] = StarEntry{j, 0u, d2};
+            if (FILL) out[cnt] = StarEntry{j, i, d2};
             ++cnt;
         }
     }
     if (!FILL && act) p.nbr_cnt[(size_t)prob * cap + i] = cnt;
+    if (FILL && act) {   // distance(q_new, q_near), rrt_star.rs:228: the nearest node is the parent the RRT kernel recorded
+        const uint32_t nearest = (uint32_t)p.parent[(size_t)prob * cap + i];
+        double c[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + nearest];
+        p.d_near[(size_t)prob * cap + i] = sqrt(dist2<DIM>(x, c, DIM));
+    }
 }
 
 // ---- exclusive prefix of the pending nodes' counts, and how many of them fit the problem's pool segment this round
@@ -111,43 +119,116 @@ __global__ __launch_bounds__(256) void star_scan_kernel(DevParams p) {
         run += c;
     }
     __syncthreads();
-    if (tid == 0) p.nbr_take[prob] = first_over;
+    if (tid == 0) {
+        const uint32_t take = first_over;
+        p.nbr_take[prob] = take;
+        // entries of the nodes taken this round (the barrier above makes the block's offsets visible)
+        p.nbr_total[prob] = take == 0 ? 0u : p.nbr_off[base + w0 + take - 1] + p.nbr_cnt[base + w0 + take - 1];
+    }
 }
 
-// ---- 2. one wave per node: its neighbours' distances and the validity of both motions; the node's distance to its
-// nearest node (the parent the RRT kernel recorded)
+// check_motion(a, b) and check_motion(b, a) at once (rrt_star.rs:73-104 twice): the two motions share their length, hence
+// their step count, and -- every interpolated state of either lies within dist/2 (+ rounding) of the midpoint -- ONE pass of
+// the conservative midpoint filter of motion_seq.hpp (margins: 1e-6 relative, 1e-9 |coordinates| absolute, against a few ulps
+// between the two directions' midpoints); only the spheres it leaves are stepped, direction by direction, with the
+// reference's own interpolation a + (b - a) s/n  resp.  b + (a - b) s/n.
+// ---- 2. a lane per neighbour pair, the round's pool segment taken linearly (full waves whatever the list lengths): the
+// distance and the validity of both motions, motion_both() with the sphere table in LDS (every lane reads the same word).
 template <int DIM>
 __global__ __launch_bounds__(256) void star_edges_kernel(DevParams p) {
-    const uint32_t prob = blockIdx.y, lane = threadIdx.x & 63u;
-    const uint32_t w0 = p.wired[prob], take = p.nbr_take[prob];
-    const uint32_t t = uni(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (t >= take) return;
-    const uint32_t i = w0 + t;
-    const size_t cap = p.cap, base = (size_t)prob * cap;
+    __shared__ double sc[DIM][64], srad[64], sthr[64];
+    const uint32_t prob = blockIdx.y, tid = threadIdx.x;
+    const uint32_t total = p.nbr_total[prob];
+    if (blockIdx.x * 256u >= total) return;
+    const uint32_t e = blockIdx.x * 256u + tid;
+    const bool act = e < total;
+    const size_t cap = p.cap;
     const double* __restrict__ tree = p.tree + (size_t)prob * DIM * cap;
-    double x[DIM];
+    StarEntry* ent = p.pool + (size_t)prob * p.pool_share + (act ? e : 0u);
+    StarEntry en = *ent;
+    double a[DIM], b[DIM];   // a = the neighbour x_j, b = the node x_i
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) x[k] = tree[(size_t)k * cap + i];
-    if (lane == 0) {
-        const uint32_t nearest = (uint32_t)p.parent[base + i];
-        double c[DIM];
+    for (int k = 0; k < DIM; ++k) { a[k] = tree[(size_t)k * cap + en.j]; b[k] = tree[(size_t)k * cap + en.flags]; }
+    const double dist = sqrt(en.d);   // distance(x_i, x_j): symmetric in its arguments, bit for bit
+    bool ab = true, ba = true;        // check_motion(neighbour, q_new) :235 / check_motion(new, neighbour) :271
+    const uint32_t ns = p.n_spheres, nb = p.n_boxes;
+    if (ns + nb != 0) {
+        const uint32_t nsteps = num_steps_u32(dist, p.res);
+        const bool single = nsteps <= 1;   // is_valid(to) only
+        const double dn = (double)nsteps;
+        double mid[DIM];
+        lerp<DIM>(a, b, 0.5, mid, DIM);
+        const double h = 0.5 * dist * (1.0 + 1e-6) + p.filt_abs;
+        for (uint32_t w0 = 0; w0 < ns; w0 += 64) {
+            const uint32_t cnt = ns - w0 < 64u ? ns - w0 : 64u;
+            __syncthreads();   // the previous chunk has been consumed
+            if (tid < cnt) {
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + nearest];
-        p.d_near[base + i] = sqrt(dist2<DIM>(x, c, DIM));   // distance(q_new, q_near), rrt_star.rs:228
+                for (int k = 0; k < DIM; ++k) sc[k][tid] = p.sph_c[(size_t)k * ns + w0 + tid];
+                srad[tid] = p.sph_r[w0 + tid];
+                sthr[tid] = p.sph_thr[w0 + tid];
+            }
+            __syncthreads();
+            if (!act) continue;
+            if (single) {
+                for (uint32_t jj = 0; jj < cnt; ++jj) {
+                    double c[DIM];
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) c[k] = sc[k][jj];
+                    if (!(dist2<DIM>(c, b, DIM) > sthr[jj])) ab = false;
+                    if (!(dist2<DIM>(c, a, DIM) > sthr[jj])) ba = false;
+                }
+                continue;
+            }
+            uint64_t mask = 0;
+            for (uint32_t jj = 0; jj < cnt; ++jj) {
+                double c[DIM];
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) c[k] = sc[k][jj];
+                const double rr = srad[jj] + h;
+                const double lim = rr * rr * (1.0 + 1e-9);
+                if (!(dist2<DIM>(c, mid, DIM) > lim)) mask |= 1ull << jj;   // NaN / inf radii stay in
+            }
+            if (mask == 0) continue;
+            for (uint32_t step = 1; step <= nsteps && (ab || ba); ++step) {
+                const double t = (double)step / dn;
+                double s1[DIM], s2[DIM];
+                lerp<DIM>(a, b, t, s1, DIM);
+                lerp<DIM>(b, a, t, s2, DIM);
+                for (uint64_t m = mask; m != 0; m &= m - 1) {
+                    const uint32_t o = (uint32_t)(__ffsll((unsigned long long)m) - 1);
+                    double c[DIM];
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) c[k] = sc[k][o];
+                    if (!(dist2<DIM>(c, s1, DIM) > sthr[o])) ab = false;
+                    if (!(dist2<DIM>(c, s2, DIM) > sthr[o])) ba = false;
+                }
+            }
+        }
+        if (nb != 0 && act) {   // boxes are never filtered
+            if (single) {
+                for (uint32_t bx = 0; bx < nb; ++bx) {
+                    if (obstacle_hit<DIM>(p, DIM, b, ns + bx)) ab = false;
+                    if (obstacle_hit<DIM>(p, DIM, a, ns + bx)) ba = false;
+                }
+            } else {
+                for (uint32_t step = 1; step <= nsteps && (ab || ba); ++step) {
+                    const double t = (double)step / dn;
+                    double s1[DIM], s2[DIM];
+                    lerp<DIM>(a, b, t, s1, DIM);
+                    lerp<DIM>(b, a, t, s2, DIM);
+                    for (uint32_t bx = 0; bx < nb; ++bx) {
+                        if (ab && obstacle_hit<DIM>(p, DIM, s1, ns + bx)) ab = false;
+                        if (ba && obstacle_hit<DIM>(p, DIM, s2, ns + bx)) ba = false;
+                    }
+                }
+            }
+        }
     }
-    const uint32_t cnt = p.nbr_cnt[base + i];
-    StarEntry* list = p.pool + (size_t)prob * p.pool_share + p.nbr_off[base + i];
-    for (uint32_t e = lane; e < cnt; e += 64) {
-        StarEntry en = list[e];
-        double c[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + en.j];
-        uint32_t f = 0;
-        if (motion_valid_seq<DIM>(p, c, x)) f |= 1u;   // check_motion(neighbour, q_new), rrt_star.rs:235
-        if (motion_valid_seq<DIM>(p, x, c)) f |= 2u;   // check_motion(new, neighbour), rrt_star.rs:271
-        en.flags = f;
-        en.d = sqrt(en.d);
-        list[e] = en;
+    if (act) {
+        en.flags = (ab ? 1u : 0u) | (ba ? 2u : 0u);
+        en.d = dist;
+        *ent = en;
     }
 }
 
@@ -160,61 +241,92 @@ __device__ __forceinline__ uint64_t wave_sum_u64_shfl(uint64_t v) {
     return v;
 }
 
-// ---- 3. one wave per problem: rrt_star.rs:225-282 for the nodes [wired, wired + take) in insertion order
+// ---- 3. one wave per problem: rrt_star.rs:225-282 for the nodes [wired, wired + take) in insertion order.  A node costs one
+// memory round trip: its metadata comes 64 nodes at a time (a lane per node, read back with v_readlane), its first 64
+// neighbour entries were requested while the node before it was being wired (entries never change), so only the costs --
+// which the node before it may just have rewired -- are fetched on the spot.  Loads after stores of the same wave see
+// them (vector memory operations of a wave execute in order; the stores write through the CU's own L1).
 __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
     const uint32_t prob = blockIdx.x, lane = threadIdx.x;
     const uint32_t w0 = p.wired[prob], take = p.nbr_take[prob];
     if (take == 0) return;
+    const uint32_t end = w0 + take;
     const size_t cap = p.cap, base = (size_t)prob * cap;
     double* cost = p.cost + base;
     int32_t* parent = p.parent + base;
     const StarEntry* pool = p.pool + (size_t)prob * p.pool_share;
     uint64_t W = p.wire_chk[prob];
-    for (uint32_t i = w0; i < w0 + take; ++i) {
-        const uint32_t cnt = uni(p.nbr_cnt[base + i]);
-        const StarEntry* list = pool + p.nbr_off[base + i];
-        const uint32_t nearest = uni((uint32_t)parent[i]);
-        // 6. choose parent: cost(temp_node, q_near_node) first (:228), then the neighbours in ascending index with the running minimum
-        const double c0 = unid(cost[nearest] + p.d_near[base + i]);
-        double best_c = c0;
-        uint32_t best_j = nearest;
-        for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
-            const bool has = e0 + lane < cnt;
-            const StarEntry en = list[has ? e0 + lane : 0u];
-            const double c = cost[en.j] + en.d;                          // cost(temp_node, neighbour), :104-113
-            const bool cand = has && (en.flags & 1u) != 0 && c < best_c;   // strict: an equal cost keeps the earlier choice
-            const double cm = wave_min_f64(cand ? c : __builtin_inf());
-            const uint64_t m = __ballot(cand && c == cm);
-            if (m != 0) {   // the trip's cheapest valid candidate, lowest index among equals (the list is ascending)
-                const int l = __ffsll((unsigned long long)m) - 1;
-                best_c = unid(cm);
-                best_j = (uint32_t)__builtin_amdgcn_readlane((int)en.j, l);
+    const StarEntry none{0u, 0u, 0.0};
+    for (uint32_t i0 = w0; i0 < end; i0 += 64) {
+        const uint32_t t = i0 + lane;
+        const bool mine = t < end;
+        const uint32_t m_cnt = mine ? p.nbr_cnt[base + t] : 0u, m_off = mine ? p.nbr_off[base + t] : 0u;
+        const uint32_t m_near = mine ? (uint32_t)parent[t] : 0u;   // still the nearest node: the RRT kernel's parent
+        const double m_dn = mine ? p.d_near[base + t] : 0.0;
+        const uint32_t nb = end - i0 < 64u ? end - i0 : 64u;
+        uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)m_cnt, 0);
+        const StarEntry* list = pool + (uint32_t)__builtin_amdgcn_readlane((int)m_off, 0);
+        StarEntry nxt = lane < cnt ? list[lane] : none;
+        for (uint32_t u = 0; u < nb; ++u) {
+            const uint32_t i = i0 + u;
+            const StarEntry cur = nxt;   // entries [0, 64) of node i
+            const uint32_t nearest = (uint32_t)__builtin_amdgcn_readlane((int)m_near, (int)u);
+            const double dn = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m_dn), (int)u), __builtin_amdgcn_readlane(__double2loint(m_dn), (int)u));
+            const StarEntry* list_i = list;
+            const uint32_t cnt_i = cnt;
+            if (u + 1 < nb) {   // the next node's first entries: requested now, used in the next trip
+                cnt = (uint32_t)__builtin_amdgcn_readlane((int)m_cnt, (int)(u + 1));
+                list = pool + (uint32_t)__builtin_amdgcn_readlane((int)m_off, (int)(u + 1));
+                nxt = lane < cnt ? list[lane] : none;
             }
+            // 6. choose parent: cost(temp_node, q_near_node) first (:228), then the neighbours in ascending index with the running minimum
+            const bool has0 = lane < cnt_i;
+            const double cj0 = has0 ? cost[cur.j] : 0.0;
+            const double c0 = unid(cost[nearest] + dn);
+            double best_c = c0;
+            uint32_t best_j = nearest;
+            for (uint32_t e0 = 0; e0 < cnt_i; e0 += 64) {
+                const bool has = e0 + lane < cnt_i;
+                const StarEntry en = e0 == 0 ? cur : (has ? list_i[e0 + lane] : none);
+                const double cj = e0 == 0 ? cj0 : (has ? cost[en.j] : 0.0);
+                const double c = cj + en.d;                                   // cost(temp_node, neighbour), :104-113
+                const bool cand = has && (en.flags & 1u) != 0 && c < best_c;   // strict: an equal cost keeps the earlier choice
+                const double cm = wave_min_f64(cand ? c : __builtin_inf());
+                const uint64_t m = __ballot(cand && c == cm);
+                if (m != 0) {   // the trip's cheapest valid candidate, lowest index among equals (the list is ascending)
+                    const int l = __ffsll((unsigned long long)m) - 1;
+                    best_c = unid(cm);
+                    best_j = (uint32_t)__shfl((int)en.j, l, 64);
+                }
+            }
+            // 7. push: parent and cost of the new node (:244-250)
+            if (lane == 0) { parent[i] = (int32_t)best_j; cost[i] = best_c; }
+            // 8. rewire (:253-282)
+            uint64_t rew_cnt = 0, rew_sum = 0;
+            for (uint32_t e0 = 0; e0 < cnt_i; e0 += 64) {
+                const bool has = e0 + lane < cnt_i;
+                const StarEntry en = e0 == 0 ? cur : (has ? list_i[e0 + lane] : none);
+                const double cj = e0 == 0 ? cj0 : (has ? cost[en.j] : 0.0);
+                const double c2 = best_c + en.d;                              // cost(neighbour, new_node), :265
+                const bool rw = has && en.j != best_j && c2 < cj && (en.flags & 2u) != 0;
+                if (rw) { parent[en.j] = (int32_t)i; cost[en.j] = c2; }
+                const uint64_t rm = __ballot(rw);
+                if (rm != 0) {
+                    rew_cnt += (uint64_t)__popcll(rm);
+                    rew_sum += wave_sum_u64_shfl(rw ? (uint64_t)en.j : 0ull);
+                }
+            }
+            uint64_t w = fnv_mix(kFnvBasis, (uint64_t)best_j);
+            w = fnv_mix(w, (uint64_t)__double_as_longlong(best_c));
+            w = fnv_mix(w, rew_cnt);
+            w = fnv_mix(w, rew_sum);
+            W = W * kFnvPrime + w;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // program order for the compiler; the hardware keeps a wave's memory operations in order
         }
-        // 7. push: parent and cost of the new node (:244-250)
-        if (lane == 0) { parent[i] = (int32_t)best_j; cost[i] = best_c; }
-        // 8. rewire (:253-282)
-        uint64_t rew_cnt = 0, rew_sum = 0;
-        for (uint32_t e0 = 0; e0 < cnt; e0 += 64) {
-            const bool has = e0 + lane < cnt;
-            const StarEntry en = list[has ? e0 + lane : 0u];
-            const double c2 = best_c + en.d;                             // cost(neighbour, new_node), :265
-            const bool rw = has && en.j != best_j && c2 < cost[en.j] && (en.flags & 2u) != 0;
-            if (rw) { parent[en.j] = (int32_t)i; cost[en.j] = c2; }
-            rew_cnt += (uint64_t)__popcll(__ballot(rw));
-            rew_sum += wave_sum_u64_shfl(rw ? (uint64_t)en.j : 0ull);
-        }
-        uint64_t w = fnv_mix(kFnvBasis, (uint64_t)best_j);
-        w = fnv_mix(w, (uint64_t)__double_as_longlong(best_c));
-        w = fnv_mix(w, rew_cnt);
-        w = fnv_mix(w, rew_sum);
-        W = W * kFnvPrime + w;
-        // this wave's stores to cost / parent are complete before the next node reads them (same CU: a wait, no cache op)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
     if (lane == 0) {
         p.wire_chk[prob] = W;
-        p.wired[prob] = w0 + take;
+        p.wired[prob] = end;
     }
 }
 
@@ -238,9 +350,9 @@ void launch_star_fill(const DevParams& p, uint32_t max_take, hipStream_t stream)
 void launch_star_scan(const DevParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(star_scan_kernel, dim3(p.n_problems), dim3(256), 0, stream, p);
 }
-void launch_star_edges(const DevParams& p, uint32_t max_take, hipStream_t stream) {
-    if (max_take == 0) return;
-    dim3 grid((max_take + 3) / 4, p.n_problems), block(256);
+void launch_star_edges(const DevParams& p, uint32_t max_total, hipStream_t stream) {
+    if (max_total == 0) return;
+    dim3 grid((max_total + 255) / 256, p.n_problems), block(256);
     switch (p.dim) {
         case 2: hipLaunchKernelGGL(star_edges_kernel<2>, grid, block, 0, stream, p); break;
         case 3: hipLaunchKernelGGL(star_edges_kernel<3>, grid, block, 0, stream, p); break;
