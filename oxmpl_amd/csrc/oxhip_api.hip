@@ -255,7 +255,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     }
     b->kernel_kind = kind;
     b->last_kind = kind;
-    if ((cfg->planner == OXHIP_PLANNER_RRT && kind == OXHIP_KERNEL_STREAM) || (cfg->planner == OXHIP_PLANNER_RRT_STAR && !b->star_wired)) {
+    if ((cfg->planner == OXHIP_PLANNER_RRT && kind == OXHIP_KERNEL_STREAM) || cfg->planner == OXHIP_PLANNER_RRT_STAR) {
         // the streaming kernels screen their scans over an fl32 shadow of the tree, which they maintain themselves
         hipError_t e2 = b->tree32.alloc((size_t)P * dim * cap);
         if (e2 == hipSuccess) e2 = b->shadow_state.alloc((size_t)P * 2);
@@ -510,6 +510,9 @@ static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
             max_pending = pend > max_pending ? pend : max_pending;
         }
         if (max_pending == 0) return OXHIP_OK;
+        uint32_t max_n = 0;
+        for (uint32_t p = 0; p < P; ++p) max_n = states[p].n_nodes > max_n ? states[p].n_nodes : max_n;
+        launch_star_shadow(b->dp, max_n, b->stream);
         launch_star_count(b->dp, max_pending, b->stream);
         launch_star_scan(b->dp, b->stream);
         HIP_TRY(hipGetLastError());

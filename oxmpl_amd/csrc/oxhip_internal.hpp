@@ -38,6 +38,7 @@ void launch_rrt_star(const DevParams& p, hipStream_t stream);
 
 // rrt_star_wire.hip: the wiring stages of the decoupled RRT* (the geometry comes from launch_rrt_lanes)
 bool star_wire_supported(uint32_t dim);
+void launch_star_shadow(const DevParams& p, uint32_t max_nodes, hipStream_t stream);   // tree32 and its magnitude bound, nodes [0, n)
 void launch_star_count(const DevParams& p, uint32_t max_pending, hipStream_t stream);   // nbr_cnt of the nodes [wired, n)
 void launch_star_scan(const DevParams& p, hipStream_t stream);                          // nbr_off, nbr_take
 void launch_star_fill(const DevParams& p, uint32_t max_take, hipStream_t stream);       // the lists of [wired, wired + take)

@@ -29,9 +29,34 @@ namespace oxhip {
 
 constexpr int kPairThreads = 256;
 
+// ---- 0. binary32 copy of the node positions (what the pair search screens with) and the largest magnitude among them
+template <int DIM>
+__global__ __launch_bounds__(256) void star_shadow_kernel(DevParams p) {
+    const uint32_t prob = blockIdx.y, i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = p.state[prob].n_nodes;
+    if (i >= n) return;
+    const size_t cap = p.cap;
+    uint32_t mab = 0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const float f = (float)p.tree[((size_t)prob * DIM + k) * cap + i];
+        p.tree32[((size_t)prob * DIM + k) * cap + i] = f;
+        const uint32_t ab = __builtin_bit_cast(uint32_t, f) & 0x7FFFFFFFu;
+        mab = ab > mab ? ab : mab;
+    }
+    atomicMax(&p.shadow_state[2 * (size_t)prob + 1], mab);   // (non-negative floats order like their bit patterns; NaN sorts last: unusable)
+}
+
+typedef float sw_f32x2 __attribute__((ext_vector_type(2)));
+
 // ---- 1. neighbour lists.  A thread owns node i and walks j = 0 .. i-1; the 64 nodes of a wave are consecutive, j is
-// wave-uniform (x_j comes through the scalar cache).  FILL = false counts, FILL = true writes (j, i, d2) at the node's offset
-// (the owner i rides in the flags word until the edge kernel replaces it) and the node's distance to its nearest node.
+// wave-uniform (x_j comes through the scalar cache).  32 nodes j per trip are SCREENED in packed binary32 (two j per
+// instruction: difference, square, fused multiply-add -- the screen of rrt_stream.hip / rrt_star.hip, error model and
+// threshold of rrt_device.hpp: a pair inside the radius cannot show a binary32 squared distance above screen_threshold);
+// the trip's hits are kept as a bit mask and only they -- 0.7 % of the pairs at radius 1 in configs[1]'s world -- get the
+// reference's binary64 test d2 <= T(search_radius) (rrt_star.rs:125), in ascending j.  FILL = false counts, FILL = true
+// writes (j, i, d2) at the node's offset (the owner i rides in the flags word until the edge kernel replaces it) and the
+// node's distance to its nearest node.
 template <int DIM, bool FILL>
 __global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
     const uint32_t prob = blockIdx.y;
@@ -44,40 +69,53 @@ __global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
     const bool act = i < hi;
     const size_t cap = p.cap;
     const double* __restrict__ tree = p.tree + (size_t)prob * DIM * cap;
+    const float* __restrict__ t32 = p.tree32 + (size_t)prob * DIM * cap;
     double x[DIM];
+    float xf[DIM];
 #pragma unroll
-    for (int k = 0; k < DIM; ++k) x[k] = tree[(size_t)k * cap + (act ? i : w0)];
+    for (int k = 0; k < DIM; ++k) {
+        x[k] = tree[(size_t)k * cap + (act ? i : w0)];
+        xf[k] = t32[(size_t)k * cap + (act ? i : w0)];
+    }
     const uint32_t last = hi - 1u < wave_first + 63u ? hi - 1u : wave_first + 63u;   // the wave's largest node: j < last
     const double thr = p.thr_search;
+    float thr32;
+    {
+        const double m_all = (double)__builtin_bit_cast(float, p.shadow_state[2 * (size_t)prob + 1]) * (1.0 + 0x1p-23);
+        thr32 = screen_threshold(screen_margins(m_all, DIM), sqrt(thr));   // +inf when the screen cannot be used
+    }
+    const bool screen = thr32 < __builtin_inff();
     uint32_t cnt = 0;
     StarEntry* __restrict__ out = nullptr;
     if (FILL && act) out = p.pool + (size_t)prob * p.pool_share + p.nbr_off[(size_t)prob * cap + i];
-    uint32_t j = 0;
-    for (; j + 4 <= last; j += 4) {   // four wave-uniform nodes per trip
-        double d2[4];
+    for (uint32_t j0 = 0; j0 < last; j0 += 32) {   // (rows are padded to cap: a trip may read up to 31 floats past `last`, masked below)
+        uint32_t bits = screen ? 0u : 0xFFFFFFFFu;   // (no usable screen -- coordinates beyond binary32's range --: every pair gets the exact test)
+        if (screen)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < 32; t += 2) {
+            sw_f32x2 s;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k) {
+                const sw_f32x2 cj = *reinterpret_cast<const sw_f32x2*>(t32 + (size_t)k * cap + j0 + t);   // wave-uniform address
+                const sw_f32x2 e = cj - xf[k];
+                s = k == 0 ? e * e : __builtin_elementwise_fma(e, e, s);
+            }
+            bits |= (s[0] <= thr32 ? (1u << t) : 0u) | (s[1] <= thr32 ? (2u << t) : 0u);
+        }
+        // only nodes before this lane's own count (j < i)
+        const uint32_t lim = (act && i > j0) ? (i - j0 >= 32u ? 0xFFFFFFFFu : ((1u << (i - j0)) - 1u)) : 0u;
+        bits &= lim;
+        if (__ballot(bits != 0) == 0) continue;
+        for (; bits != 0; bits &= bits - 1) {   // ascending j
+            const uint32_t j = j0 + (uint32_t)(__ffs((int)bits) - 1);
             double c[DIM];
 #pragma unroll
-            for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + j + t];
-            d2[t] = dist2<DIM>(x, c, DIM);   // distance(node.state, tree[j].state), rrt_star.rs:125
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (act && j + t < i && d2[t] <= thr) {
-                if (FILL) out[cnt] = StarEntry{j + (uint32_t)t, i, d2[t]};
+            for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + j];
+            const double d2 = dist2<DIM>(x, c, DIM);   // distance(node.state, tree[j].state), rrt_star.rs:125
+            if (d2 <= thr) {
+                if (FILL) out[cnt] = StarEntry{j, i, d2};
                 ++cnt;
             }
-        }
-    }
-    for (; j < last; ++j) {
-        double c[DIM];
-#pragma unroll
-        for (int k = 0; k < DIM; ++k) c[k] = tree[(size_t)k * cap + j];
-        const double d2 = dist2<DIM>(x, c, DIM);
-        if (act && j < i && d2 <= thr) {
-            if (FILL) out[cnt] = StarEntry{j, i, d2};
-            ++cnt;
         }
     }
     if (!FILL && act) p.nbr_cnt[(size_t)prob * cap + i] = cnt;
@@ -342,6 +380,18 @@ static void launch_pairs(const DevParams& p, uint32_t max_nodes, hipStream_t str
         case 4: hipLaunchKernelGGL((star_pairs_kernel<4, FILL>), grid, block, 0, stream, p); break;
         case 5: hipLaunchKernelGGL((star_pairs_kernel<5, FILL>), grid, block, 0, stream, p); break;
         case 6: hipLaunchKernelGGL((star_pairs_kernel<6, FILL>), grid, block, 0, stream, p); break;
+        default: break;
+    }
+}
+void launch_star_shadow(const DevParams& p, uint32_t max_nodes, hipStream_t stream) {
+    if (max_nodes == 0) return;
+    dim3 grid((max_nodes + 255) / 256, p.n_problems), block(256);
+    switch (p.dim) {
+        case 2: hipLaunchKernelGGL(star_shadow_kernel<2>, grid, block, 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(star_shadow_kernel<3>, grid, block, 0, stream, p); break;
+        case 4: hipLaunchKernelGGL(star_shadow_kernel<4>, grid, block, 0, stream, p); break;
+        case 5: hipLaunchKernelGGL(star_shadow_kernel<5>, grid, block, 0, stream, p); break;
+        case 6: hipLaunchKernelGGL(star_shadow_kernel<6>, grid, block, 0, stream, p); break;
         default: break;
     }
 }
