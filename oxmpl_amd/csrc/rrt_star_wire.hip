@@ -270,15 +270,6 @@ __global__ __launch_bounds__(256) void star_edges_kernel(DevParams p) {
     }
 }
 
-__device__ __forceinline__ uint64_t wave_sum_u64_shfl(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-        v += ((uint64_t)hi << 32) | lo;
-    }
-    return v;
-}
-
 // ---- 3. one wave per problem: rrt_star.rs:225-282 for the nodes [wired, wired + take) in insertion order.  A node costs one
 // memory round trip: its metadata comes 64 nodes at a time (a lane per node, read back with v_readlane), its first 64
 // neighbour entries were requested while the node before it was being wired (entries never change), so only the costs --
@@ -329,13 +320,15 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
                 const double cj = e0 == 0 ? cj0 : (has ? cost[en.j] : 0.0);
                 const double c = cj + en.d;                                   // cost(temp_node, neighbour), :104-113
                 const bool cand = has && (en.flags & 1u) != 0 && c < best_c;   // strict: an equal cost keeps the earlier choice
-                const double cm = wave_min_f64(cand ? c : __builtin_inf());
-                const uint64_t m = __ballot(cand && c == cm);
-                if (m != 0) {   // the trip's cheapest valid candidate, lowest index among equals (the list is ascending)
-                    const int l = __ffsll((unsigned long long)m) - 1;
-                    best_c = unid(cm);
-                    best_j = (uint32_t)__shfl((int)en.j, l, 64);
+                uint64_t m = __ballot(cand);
+                if (m == 0) continue;                        // (usual for a node whose nearest node is also its best parent)
+                if ((m & (m - 1)) != 0) {                    // several candidates: the cheapest, lowest index among equals (the list is ascending)
+                    const double cm = wave_min_f64(cand ? c : __builtin_inf());
+                    m = __ballot(cand && c == cm);
                 }
+                const int l = __ffsll((unsigned long long)m) - 1;
+                best_c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c), l), __builtin_amdgcn_readlane(__double2loint(c), l));
+                best_j = (uint32_t)__builtin_amdgcn_readlane((int)en.j, l);
             }
             // 7. push: parent and cost of the new node (:244-250)
             if (lane == 0) { parent[i] = (int32_t)best_j; cost[i] = best_c; }
@@ -348,11 +341,10 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
                 const double c2 = best_c + en.d;                              // cost(neighbour, new_node), :265
                 const bool rw = has && en.j != best_j && c2 < cj && (en.flags & 2u) != 0;
                 if (rw) { parent[en.j] = (int32_t)i; cost[en.j] = c2; }
-                const uint64_t rm = __ballot(rw);
-                if (rm != 0) {
-                    rew_cnt += (uint64_t)__popcll(rm);
-                    rew_sum += wave_sum_u64_shfl(rw ? (uint64_t)en.j : 0ull);
-                }
+                uint64_t rm = __ballot(rw);
+                rew_cnt += (uint64_t)__popcll(rm);
+                for (; rm != 0; rm &= rm - 1)   // (a few lanes at most)
+                    rew_sum += (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)en.j, __ffsll((unsigned long long)rm) - 1);
             }
             uint64_t w = fnv_mix(kFnvBasis, (uint64_t)best_j);
             w = fnv_mix(w, (uint64_t)__double_as_longlong(best_c));
