@@ -58,7 +58,11 @@ typedef enum oxhip_stop_reason {
 typedef enum oxhip_planner_kind {
     OXHIP_PLANNER_RRT = 0,         /* geometric::RRT         oxmpl/src/geometric/planners/rrt.rs */
     OXHIP_PLANNER_RRT_CONNECT = 1, /* geometric::RRTConnect  oxmpl/src/geometric/planners/rrt_connect.rs (stream kernel only) */
-    OXHIP_PLANNER_RRT_STAR = 2     /* geometric::RRTStar     oxmpl/src/geometric/planners/rrt_star.rs (stream kernel only) */
+    OXHIP_PLANNER_RRT_STAR = 2     /* geometric::RRTStar     oxmpl/src/geometric/planners/rrt_star.rs.  kernel = OXHIP_KERNEL_AUTO /
+                                      OXHIP_KERNEL_LANES: the decoupled design (the node positions of an RRT* run are RRT's, so the
+                                      lane-per-query kernel grows the tree and rrt_star_wire.hip then chooses parents and rewires:
+                                      R^2 .. R^6, trees that fit the register rows); OXHIP_KERNEL_STREAM: rrt_star.hip, everything
+                                      in one kernel (any dimension <= 8, any size).  Same results bit for bit. */
 } oxhip_planner_kind;
 
 /* State space of a batch.  oxmpl has RealVectorStateSpace, SO2StateSpace and SO3StateSpace; SE(2) is not in the

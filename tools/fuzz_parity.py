@@ -58,6 +58,8 @@ def case_rv(planner):
         kernels += [capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32]
     if planner == capi.PLANNER_RRT and 2 <= dim <= 6:
         kernels += [capi.KERNEL_LANES, capi.KERNEL_LANES, capi.KERNEL_AUTO]   # the default path: weighted up
+    if planner == capi.PLANNER_RRT_STAR and 2 <= dim <= 6:
+        kernels += [capi.KERNEL_AUTO, capi.KERNEL_AUTO]   # RRT*: the decoupled design (rrt_lanes.hip + rrt_star_wire.hip) where it exists
     kernel = int(rng.choice(kernels))
     desc = dict(planner=planner, kernel=kernel, dim=dim, lo=lo, hi=hi, md=md, gb=gb, frac=frac, ns=len(sr), nb=len(blo),
                 seed=seed, pid0=pid0, nprob=nprob, max_nodes=max_nodes, iters=iters, stop=stop, radius=radius)
@@ -216,12 +218,19 @@ def case_se2():
 CASES = [("rrt", lambda: case_rv(capi.PLANNER_RRT)), ("rrt", lambda: case_rv(capi.PLANNER_RRT)),
          ("rrt_connect", lambda: case_rv(capi.PLANNER_RRT_CONNECT)), ("rrt_star", lambda: case_rv(capi.PLANNER_RRT_STAR)),
          ("prm", case_prm), ("se2_connect", case_se2)]
+if len(sys.argv) > 3:   # third argument: only this planner's cases (e.g. rrt_star)
+    CASES = [c for c in CASES if c[0] == sys.argv[3]]
 t0 = time.perf_counter()
 i = 0
+slowest = 0.0
 while time.perf_counter() - t0 < BUDGET:
     name, fn = CASES[i % len(CASES)]
     i += 1
+    t_case = time.perf_counter()
     r = fn()
+    if time.perf_counter() - t_case > slowest:
+        slowest = time.perf_counter() - t_case
+        print("slowest case so far: %s %.2f s" % (name, slowest), flush=True)
     if r is None:
         continue
     counts[name] = counts.get(name, 0) + 1
