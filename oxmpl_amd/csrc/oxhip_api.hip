@@ -202,7 +202,11 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             uint64_t share = 64ull * cap;
             const uint64_t budget_entries = (24ull << 30) / sizeof(StarEntry) / P;
             if (share > budget_entries) share = budget_entries;
-            if (share < cap) share = cap;
+            if (const char* e = std::getenv("OXHIP_STAR_POOL_SHARE")) {   // tests: a small segment forces many wiring rounds
+                const uint64_t v = std::strtoull(e, nullptr, 0);
+                if (v != 0 && v < share) share = v;
+            }
+            if (share < cap) share = cap;   // a single list is at most cap entries long: every round wires at least one node
             dp.pool_share = (uint32_t)share;
             chk(b->pool.alloc((size_t)P * share));
             chk(b->wired.alloc(P));

@@ -417,6 +417,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
             for (int g0 = 0; g0 < S; g0 += 4) {
                 if ((uint32_t)g0 < nrows) {
+                    if constexpr (DIM <= 5) {
 #pragma unroll
                     for (int sp = g0 / 2; sp < g0 / 2 + 2; ++sp) {
                         // a packed fused multiply-add covers the two ROWS of a register pair for one query (op_sel broadcasts the
@@ -439,6 +440,29 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) vmin3_f32(b1[b0 + t], acc[t][0], acc[t][1]);
                         }
+                    }
+                    } else {
+                    // R^6 (four queries per pass, 20 x 7 registers of tree): the form that needs four accumulator registers
+                    // instead of eight -- the row is the broadcast half, a packed instruction covers a query PAIR, one v_min_f32
+                    // per (row, query) -- because here every register saved is a spill saved (190 M it/s against 127 M)
+#pragma unroll
+                    for (int s = g0; s < g0 + 4; ++s) {
+                        lf32x2 acc[kPassQ / 2];
+#pragma unroll
+                        for (int bp = 0; bp < kPassQ / 2; ++bp)
+                            acc[bp] = (s & 1) ? __builtin_shufflevector(tcc[s / 2], tcc[s / 2], 1, 1) : __builtin_shufflevector(tcc[s / 2], tcc[s / 2], 0, 0);
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const lf32x2 a = (s & 1) ? __builtin_shufflevector(tr[k][s / 2], tr[k][s / 2], 1, 1) : __builtin_shufflevector(tr[k][s / 2], tr[k][s / 2], 0, 0);
+#pragma unroll
+                            for (int bp = 0; bp < kPassQ / 2; ++bp) acc[bp] = __builtin_elementwise_fma(a, q[bp][k], acc[bp]);
+                        }
+#pragma unroll
+                        for (int bp = 0; bp < kPassQ / 2; ++bp) {
+                            vmin_f32(b1[2 * bp], acc[bp][0]);
+                            vmin_f32(b1[2 * bp + 1], acc[bp][1]);
+                        }
+                    }
                     }
                 }
             }

@@ -192,3 +192,22 @@ def test_rrt_star_argument_validation():
     g.setup([0.1, 0.1], [0.9, 0.9], 0.1)
     with pytest.raises(capi.OxhipError):
         g.costs(0)          # not an RRT* batch
+
+
+def test_rrt_star_wiring_in_many_rounds(star_golden, star_design, monkeypatch):
+    """the decoupled design wires, per round, the longest prefix of a problem's pending nodes whose neighbour lists fit its
+    pool segment: with the segment cut to its minimum (one list's worst case) and every node a neighbour of every later one,
+    a 900-node tree needs hundreds of rounds -- and must come out exactly as in one"""
+    if star_design != "decoupled":
+        pytest.skip("the pool belongs to the decoupled design")
+    monkeypatch.setenv("OXHIP_STAR_POOL_SHARE", "1")   # clamped up to the node capacity (1024 entries)
+    P = dict(star_golden["config2"]["params"], search_radius=float("inf"), max_nodes=900)
+    g = make_gpu(P, 3, 77, 5, stop=False)
+    g.solve(400)
+    g.solve(10 ** 6)
+    c = g.counts()
+    assert (c["nodes"] == 900).all()
+    for p in range(3):
+        o = make_oracle(P, 77, 5 + p, stop=False)
+        o.solve(10 ** 6)
+        assert_same(g, p, o, c)
