@@ -46,6 +46,8 @@ struct oxhip_rrt_batch {
     DevBuf<uint32_t> wired, nbr_cnt, nbr_off, nbr_take, nbr_total;
     DevBuf<double> d_near, sph_r;
     DevBuf<StarEntry> pool;
+    DevBuf<StarChunk> chunks;
+    DevBuf<uint32_t> chunk_cursor;
     bool star_wired = false;        // RRT*: geometry by rrt_lanes.hip + the wiring kernels (else rrt_star.hip)
     DevBuf<float> tree32;           // stream / RRT* kernels: fl32 shadow of the tree
     DevBuf<uint32_t> shadow_state;  // [P][2]
@@ -209,6 +211,9 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             if (share < cap) share = cap;   // a single list is at most cap entries long: every round wires at least one node
             dp.pool_share = (uint32_t)share;
             chk(b->pool.alloc((size_t)P * share));
+            dp.chunk_share = (uint32_t)(share / 32 + cap);   // enough for any set of lists that fits the pool segment (one partial chunk per node)
+            chk(b->chunks.alloc((size_t)P * dp.chunk_share));
+            chk(b->chunk_cursor.alloc(P));
             chk(b->wired.alloc(P));
             chk(b->nbr_take.alloc(P));
             chk(b->nbr_total.alloc(P));
@@ -233,6 +238,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.cost = b->cost.p; dp.nb_idx = b->nb_idx.p; dp.nb_dist = b->nb_dist.p;
     dp.wire_chk = b->wire_chk.p; dp.wired = b->wired.p; dp.nbr_cnt = b->nbr_cnt.p; dp.nbr_off = b->nbr_off.p;
     dp.nbr_take = b->nbr_take.p; dp.nbr_total = b->nbr_total.p; dp.d_near = b->d_near.p; dp.pool = b->pool.p;
+    dp.chunks = b->chunks.p; dp.chunk_cursor = b->chunk_cursor.p;
     dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p;
 
     uint32_t kind = cfg->kernel;
@@ -502,7 +508,7 @@ static int32_t read_states(oxhip_rrt_batch* b, std::vector<ProblemState>& states
 static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
     const uint32_t P = b->cfg.n_problems;
     std::vector<ProblemState> states;
-    std::vector<uint32_t> wired(P), take(P), total(P);
+    std::vector<uint32_t> wired(P), take(P), total(P), chunks_used(P);
     for (;;) {
         int32_t st = read_states(b, states);
         if (st != OXHIP_OK) return st;
@@ -517,6 +523,7 @@ static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
         uint32_t max_n = 0;
         for (uint32_t p = 0; p < P; ++p) max_n = states[p].n_nodes > max_n ? states[p].n_nodes : max_n;
         launch_star_shadow(b->dp, max_n, b->stream);
+        HIP_TRY(hipMemsetAsync(b->chunk_cursor.p, 0, (size_t)P * sizeof(uint32_t), b->stream));
         launch_star_count(b->dp, max_pending, b->stream);
         launch_star_scan(b->dp, b->stream);
         HIP_TRY(hipGetLastError());
@@ -529,7 +536,19 @@ static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
             max_total = total[p] > max_total ? total[p] : max_total;
         }
         if (max_take == 0) return fail(OXHIP_ERR_HIP, "RRT* wiring: no node fits the neighbour pool");   // (a list is at most cap <= pool_share long)
-        launch_star_fill(b->dp, max_take, b->stream);
+        // every pending node of every problem fits this round and the counting pass could keep all it found: the lists are
+        // built from its chunks; otherwise (a pool segment or the chunk store ran out) the round searches a second time
+        HIP_TRY(hipMemcpyAsync(chunks_used.data(), b->chunk_cursor.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        bool one_pass = std::getenv("OXHIP_STAR_TWO_PASS") == nullptr;
+        uint32_t max_chunks = 0;
+        for (uint32_t p = 0; p < P; ++p) {
+            const uint32_t pend = states[p].n_nodes > wired[p] ? states[p].n_nodes - wired[p] : 0u;
+            if (take[p] != pend || chunks_used[p] > b->dp.chunk_share) one_pass = false;
+            max_chunks = chunks_used[p] > max_chunks ? chunks_used[p] : max_chunks;
+        }
+        if (one_pass) launch_star_compact(b->dp, max_chunks, b->stream);
+        else launch_star_fill(b->dp, max_take, b->stream);
         launch_star_edges(b->dp, max_total, b->stream);
         launch_star_wire(b->dp, b->stream);
         HIP_TRY(hipGetLastError());

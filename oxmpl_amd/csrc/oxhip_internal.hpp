@@ -43,6 +43,7 @@ void launch_star_count(const DevParams& p, uint32_t max_pending, hipStream_t str
 void launch_star_scan(const DevParams& p, hipStream_t stream);                          // nbr_off, nbr_take
 void launch_star_fill(const DevParams& p, uint32_t max_take, hipStream_t stream);       // the lists of [wired, wired + take)
 void launch_star_edges(const DevParams& p, uint32_t max_total, hipStream_t stream);     // per pair: distance, both motions' validity
+void launch_star_compact(const DevParams& p, uint32_t max_chunks, hipStream_t stream);  // the counting pass's chunks -> the lists (instead of launch_star_fill)
 void launch_star_wire(const DevParams& p, hipStream_t stream);                          // choose parent / rewire, node by node
 
 // rrt_resident.hip

@@ -44,6 +44,12 @@ struct StarEntry {
     double d;          // distance(node, neighbour)  (the pair search leaves the squared distance here)
 };
 
+// 32 neighbours of one node as the counting pass found them (rrt_star_wire.hip): the node's list is its chunks in ordinal order
+struct StarChunk {
+    uint32_t i, cnt, seq, pad;   // owner node, entries used, ordinal within the node's list
+    uint32_t j[32];              // ascending neighbour indices
+};
+
 // kernel arguments (by value)
 struct DevParams {
     uint32_t dim, n_problems, cap, max_nodes;
@@ -89,6 +95,9 @@ struct DevParams {
     double* d_near;         // [P][cap] distance(node, its nearest node)
     struct StarEntry* pool; // [P][pool_share] neighbour lists, ascending index within a list
     uint32_t pool_share;
+    struct StarChunk* chunks; // [P][chunk_share]
+    uint32_t* chunk_cursor;   // [P] chunks handed out this round (may run past chunk_share: then the round takes the two-pass path)
+    uint32_t chunk_share;
     // PRM only (prm_kernels.hip): the midpoint filter's inputs for motions of any length
     const double* sph_r;    // [n_spheres] radii as given
     double filt_abs;        // 1e-9 * largest coordinate magnitude in play (absolute rounding margin)

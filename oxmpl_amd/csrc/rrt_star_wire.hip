@@ -28,6 +28,7 @@
 namespace oxhip {
 
 constexpr int kPairThreads = 256;
+constexpr int kChunk = 32;   // neighbour indices per chunk (StarChunk)
 
 // ---- 0. binary32 copy of the node positions (what the pair search screens with) and the largest magnitude among them
 template <int DIM>
@@ -58,7 +59,11 @@ typedef float sw_f32x2 __attribute__((ext_vector_type(2)));
 // writes (j, i, d2) at the node's offset (the owner i rides in the flags word until the edge kernel replaces it) and the
 // node's distance to its nearest node.
 template <int DIM, bool FILL>
-__global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
+__global__ __launch_bounds__(kPairThreads, 8) void star_pairs_kernel(DevParams p) {   // (8 waves per SIMD: the loop lives on scalar-load latency hiding)
+    // the counting pass also keeps what it finds: a lane collects its hits in LDS and writes them out 32 at a time as a chunk
+    // (owner node, ordinal, 32 neighbour indices) wherever the problem's chunk cursor points; when all of a round's pending
+    // nodes fit (the usual case) the edge kernel builds the lists from the chunks and the second search (FILL) is not run
+    __shared__ uint16_t hitbuf[FILL ? 1 : kChunk][FILL ? 1 : kPairThreads];   // (node indices fit 16 bits: the lane-per-query kernel holds at most 20,480 nodes)
     const uint32_t prob = blockIdx.y;
     const uint32_t n = p.state[prob].n_nodes;
     const uint32_t w0 = p.wired[prob];
@@ -85,9 +90,19 @@ __global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
         thr32 = screen_threshold(screen_margins(m_all, DIM), sqrt(thr));   // +inf when the screen cannot be used
     }
     const bool screen = thr32 < __builtin_inff();
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, nbuf = 0, seq = 0;
     StarEntry* __restrict__ out = nullptr;
     if (FILL && act) out = p.pool + (size_t)prob * p.pool_share + p.nbr_off[(size_t)prob * cap + i];
+    auto flush = [&](uint32_t c) {   // (divergent, rare: one per 32 hits of a lane)
+        const uint32_t slot = atomicAdd(&p.chunk_cursor[prob], 1u);
+        if (slot < p.chunk_share) {   // (beyond it: the host sees the cursor and falls back to the two-pass path)
+            StarChunk* ch = p.chunks + (size_t)prob * p.chunk_share + slot;
+            ch->i = i; ch->cnt = c; ch->seq = seq; ch->pad = 0;
+#pragma unroll 1
+            for (uint32_t t = 0; t < c; ++t) ch->j[t] = hitbuf[t][threadIdx.x];
+        }
+        ++seq;
+    };
     for (uint32_t j0 = 0; j0 < last; j0 += 32) {   // (rows are padded to cap: a trip may read up to 31 floats past `last`, masked below)
         uint32_t bits = screen ? 0u : 0xFFFFFFFFu;   // (no usable screen -- coordinates beyond binary32's range --: every pair gets the exact test)
         if (screen)
@@ -114,12 +129,32 @@ __global__ __launch_bounds__(kPairThreads) void star_pairs_kernel(DevParams p) {
             const double d2 = dist2<DIM>(x, c, DIM);   // distance(node.state, tree[j].state), rrt_star.rs:125
             if (d2 <= thr) {
                 if (FILL) out[cnt] = StarEntry{j, i, d2};
+                else {
+                    hitbuf[nbuf][threadIdx.x] = (uint16_t)j;
+                    if (++nbuf == (uint32_t)kChunk) { flush(nbuf); nbuf = 0; }
+                }
                 ++cnt;
             }
         }
     }
-    if (!FILL && act) p.nbr_cnt[(size_t)prob * cap + i] = cnt;
-    if (FILL && act) {   // distance(q_new, q_near), rrt_star.rs:228: the nearest node is the parent the RRT kernel recorded
+    if (!FILL) {   // the lanes' last, partly filled chunks: one cursor bump for the wave
+        const bool part = act && nbuf != 0;
+        const uint64_t pm = __ballot(part);
+        if (pm != 0) {
+            uint32_t base0 = 0;
+            if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((unsigned long long)pm) - 1)) base0 = atomicAdd(&p.chunk_cursor[prob], (uint32_t)__popcll(pm));
+            base0 = (uint32_t)__shfl((int)base0, __ffsll((unsigned long long)pm) - 1, 64);
+            const uint32_t slot = base0 + (uint32_t)__popcll(pm & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            if (part && slot < p.chunk_share) {
+                StarChunk* ch = p.chunks + (size_t)prob * p.chunk_share + slot;
+                ch->i = i; ch->cnt = nbuf; ch->seq = seq; ch->pad = 0;
+#pragma unroll 1
+                for (uint32_t t = 0; t < nbuf; ++t) ch->j[t] = hitbuf[t][threadIdx.x];
+            }
+        }
+        if (act) p.nbr_cnt[(size_t)prob * cap + i] = cnt;
+    }
+    if (act) {   // distance(q_new, q_near), rrt_star.rs:228: the nearest node is the parent the RRT kernel recorded
         const uint32_t nearest = (uint32_t)p.parent[(size_t)prob * cap + i];
         double c[DIM];
 #pragma unroll
@@ -170,6 +205,19 @@ __global__ __launch_bounds__(256) void star_scan_kernel(DevParams p) {
 // the conservative midpoint filter of motion_seq.hpp (margins: 1e-6 relative, 1e-9 |coordinates| absolute, against a few ulps
 // between the two directions' midpoints); only the spheres it leaves are stepped, direction by direction, with the
 // reference's own interpolation a + (b - a) s/n  resp.  b + (a - b) s/n.
+// ---- 1b. the counting pass's chunks -> the nodes' lists: entry t of a chunk goes to offset(node) + 32 * ordinal + t as (j, i, -)
+__global__ __launch_bounds__(256) void star_compact_kernel(DevParams p) {
+    const uint32_t prob = blockIdx.y;
+    const uint32_t nch = p.chunk_cursor[prob] < p.chunk_share ? p.chunk_cursor[prob] : p.chunk_share;
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= nch * (uint32_t)kChunk) return;
+    const StarChunk* ch = p.chunks + (size_t)prob * p.chunk_share + e / (uint32_t)kChunk;
+    const uint32_t t = e % (uint32_t)kChunk;
+    if (t >= ch->cnt) return;
+    const uint32_t i = ch->i;
+    p.pool[(size_t)prob * p.pool_share + p.nbr_off[(size_t)prob * p.cap + i] + ch->seq * (uint32_t)kChunk + t] = StarEntry{ch->j[t], i, 0.0};
+}
+
 // ---- 2. a lane per neighbour pair, the round's pool segment taken linearly (full waves whatever the list lengths): the
 // distance and the validity of both motions, motion_both() with the sphere table in LDS (every lane reads the same word).
 template <int DIM>
@@ -183,10 +231,11 @@ __global__ __launch_bounds__(256) void star_edges_kernel(DevParams p) {
     const size_t cap = p.cap;
     const double* __restrict__ tree = p.tree + (size_t)prob * DIM * cap;
     StarEntry* ent = p.pool + (size_t)prob * p.pool_share + (act ? e : 0u);
-    StarEntry en = *ent;
+    StarEntry en = *ent;   // (j, i, -)
     double a[DIM], b[DIM];   // a = the neighbour x_j, b = the node x_i
 #pragma unroll
     for (int k = 0; k < DIM; ++k) { a[k] = tree[(size_t)k * cap + en.j]; b[k] = tree[(size_t)k * cap + en.flags]; }
+    en.d = dist2<DIM>(b, a, DIM);   // distance(node.state, tree[j].state), rrt_star.rs:125: the search's own expression
     const double dist = sqrt(en.d);   // distance(x_i, x_j): symmetric in its arguments, bit for bit
     bool ab = true, ba = true;        // check_motion(neighbour, q_new) :235 / check_motion(new, neighbour) :271
     const uint32_t ns = p.n_spheres, nb = p.n_boxes;
@@ -403,6 +452,10 @@ void launch_star_edges(const DevParams& p, uint32_t max_total, hipStream_t strea
         case 6: hipLaunchKernelGGL(star_edges_kernel<6>, grid, block, 0, stream, p); break;
         default: break;
     }
+}
+void launch_star_compact(const DevParams& p, uint32_t max_chunks, hipStream_t stream) {
+    if (max_chunks == 0) return;
+    hipLaunchKernelGGL(star_compact_kernel, dim3((max_chunks * (uint32_t)kChunk + 255) / 256, p.n_problems), dim3(256), 0, stream, p);
 }
 void launch_star_wire(const DevParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(star_wire_kernel, dim3(p.n_problems), dim3(64), 0, stream, p);
