@@ -68,6 +68,9 @@ constexpr uint32_t kDepthGrow = OXHIP_DEPTH_GROW;                 // queries sam
 #ifndef OXHIP_WANT_DIV_GROW
 #define OXHIP_WANT_DIV_GROW 8   // while inserts are on the resolver starts a round when 1/this of the window is published
 #endif
+#ifndef OXHIP_LANES_TRIP
+#define OXHIP_LANES_TRIP(DIM) 2   // (R^5 / R^6 with one block per trip -- 32 registers less in the resolver, which spills there -- was measured: see DESIGN.md 5.5)
+#endif
 #ifndef OXHIP_LANES_QSGPR
 #define OXHIP_LANES_QSGPR 0   // 1: the pass's queries in scalar registers (24 v_readfirstlane per pass); 0: in vector register pairs
 #endif
@@ -658,6 +661,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     }
 
     typedef double ldouble4 __attribute__((ext_vector_type(4)));
+    constexpr int kTrip = OXHIP_LANES_TRIP(DIM);   // candidate blocks fetched per memory round trip
     // the last whole-tree answer: valid while the tree has not grown (see the exact path)
     uint32_t memo_n = 0xFFFFFFFFu, memo_idx = kNoNode;
     double memo_g = 0.0, memo_q[D];
@@ -780,27 +784,27 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         const uint32_t thread_ = cpass == 0 ? wthread : (pair ? wthread2 : 0u);
         const bool on_ = cpass == 0 ? (act && !from_memo) : pair;
 #pragma unroll
-        for (int blk0 = 0; blk0 < S / 4; blk0 += 2) {
-            uint32_t ib2[2], il2[2], sk2[2];
-            bool have2[2];
+        for (int blk0 = 0; blk0 < S / 4; blk0 += kTrip) {
+            uint32_t ib2[kTrip], il2[kTrip], sk2[kTrip];
+            bool have2[kTrip];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < kTrip; ++h) {
                 ib2[h] = blk0 + h < S / 4 ? Lay::block_base(thread_, (uint32_t)(blk0 + h)) : kNoNode;
                 have2[h] = on_ && ib2[h] < bmin;      // (kNoNode fails; nodes >= bmin come from the ring below)
                 il2[h] = have2[h] ? ib2[h] : 0u;
             }
-            if (__ballot(have2[0] || have2[1]) == 0) continue;       // a small tree fills the first blocks only
+            if (__ballot(have2[0] || have2[kTrip - 1]) == 0) continue;       // a small tree fills the first blocks only
             // the reference's sum, coordinate by coordinate (0.0 + x*x == x*x, then + y*y, ...): eight nodes' sums side by side
-            double d8[2][4];
+            double d8[kTrip][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) sk2[h] = *reinterpret_cast<const uint32_t*>(skip + il2[h]);
+            for (int h = 0; h < kTrip; ++h) sk2[h] = *reinterpret_cast<const uint32_t*>(skip + il2[h]);
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                ldouble4 ck[2];
+                ldouble4 ck[kTrip];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) ck[h] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il2[h]);
+                for (int h = 0; h < kTrip; ++h) ck[h] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il2[h]);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < kTrip; ++h) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const double df = ck[h][t] - q[k];
@@ -810,7 +814,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 }
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < kTrip; ++h) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (have2[h] && ib2[h] + (uint32_t)t < bmin && ((sk2[h] >> (8 * t)) & 0xFFu) == 0) scan_push(pd, d8[h][t], ib2[h] + (uint32_t)t);
