@@ -46,8 +46,12 @@ namespace oxhip {
 typedef float lf32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kLanesThreads = kScanThreads + 128;   // + the resolver wave + the sampler wave
-constexpr int kQRing = 128;                         // queries in flight (power of two)
-constexpr int kNRing = 256;                         // committed nodes kept in LDS (power of two, >= kQRing + 64)
+#ifndef OXHIP_LANES_QRING
+#define OXHIP_LANES_QRING 128
+#endif
+constexpr int kQRing = OXHIP_LANES_QRING;           // queries in flight (power of two)
+constexpr int kNRing = 2 * kQRing;                  // committed nodes kept in LDS (power of two, >= kQRing + 64)
+static_assert((kQRing & (kQRing - 1)) == 0 && kNRing >= kQRing + 64, "ring sizes");
 #ifndef OXHIP_LANES_PASS3
 #define OXHIP_LANES_PASS3 8
 #endif
@@ -59,7 +63,7 @@ template <int DIM> struct LanesPass { static constexpr int Q = DIM >= 6 ? 4 : (D
 #define OXHIP_LANES_TRANSPOSE_MAX 32  // rounds of at most this many lanes use the transposed sphere pre-filter (0: never)
 #endif
 #ifndef OXHIP_DEPTH_GROW
-#define OXHIP_DEPTH_GROW 64
+#define OXHIP_DEPTH_GROW 128   // (64: 402 M it/s growing configs[1]; 128: 437-441 M; a 256-query ring with 192 / 256: 440 / 427 M)
 #endif
 constexpr uint32_t kDepthGrow = OXHIP_DEPTH_GROW;                 // queries sampled ahead of the resolver while inserts are on
 #ifndef OXHIP_LANES_PRIO
