@@ -210,7 +210,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             }
             if (share < cap) share = cap;   // a single list is at most cap entries long: every round wires at least one node
             dp.pool_share = (uint32_t)share;
-            chk(b->pool.alloc((size_t)P * share));
+            chk(b->pool.alloc((size_t)P * share + 64));   // (+ padding: masked lanes of the wiring kernel read one entry past an empty list)
             dp.chunk_share = (uint32_t)(share / 32 + cap);   // enough for any set of lists that fits the pool segment (one partial chunk per node)
             chk(b->chunks.alloc((size_t)P * dp.chunk_share));
             chk(b->chunk_cursor.alloc(P));

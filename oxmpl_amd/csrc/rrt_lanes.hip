@@ -66,6 +66,9 @@ template <int DIM> struct LanesPass { static constexpr int Q = DIM >= 6 ? 4 : (D
 #define OXHIP_DEPTH_GROW 128   // (64: 402 M it/s growing configs[1]; 128: 437-441 M; a 256-query ring with 192 / 256: 440 / 427 M)
 #endif
 constexpr uint32_t kDepthGrow = OXHIP_DEPTH_GROW;                 // queries sampled ahead of the resolver while inserts are on
+#ifndef OXHIP_WINDOW_DIV
+#define OXHIP_WINDOW_DIV 8   // while a tree is small the query window is (tree size / this), at least two passes
+#endif
 #ifndef OXHIP_LANES_PRIO
 #define OXHIP_LANES_PRIO 16
 #endif
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 // committed since its scan: the window follows the tree size (n / 8, at least two passes) up to `depth`.
                 depth_now = depth;
                 if (!p.freeze) {
-                    const uint32_t dn = uni(lds_peek(&sh.committed)) / 8u;
+                    const uint32_t dn = uni(lds_peek(&sh.committed)) / (uint32_t)OXHIP_WINDOW_DIV;
                     depth_now = dn < 2u * (uint32_t)kPassQ ? 2u * (uint32_t)kPassQ : (dn < depth ? dn : depth);
                 }
                 if (js - jr_seen + 2u * (uint32_t)kPassQ <= depth_now || js == jr_seen) { go = true; break; }   // two scanner passes' worth of the window is free: refill it

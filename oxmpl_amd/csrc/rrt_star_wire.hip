@@ -334,7 +334,9 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
     int32_t* parent = p.parent + base;
     const StarEntry* pool = p.pool + (size_t)prob * p.pool_share;
     uint64_t W = p.wire_chk[prob];
-    const StarEntry none{0u, 0u, 0.0};
+    // an entry as four dwords in registers (a struct copied through a select of two addresses ends up in memory, and the
+    // "prefetch" then waits for its own load: measured, 2.2 us per node).  Lanes past the list read a valid address and are masked.
+    auto fetch = [](const StarEntry* list, uint32_t idx) { return *reinterpret_cast<const uint4*>(list + idx); };
     for (uint32_t i0 = w0; i0 < end; i0 += 64) {
         const uint32_t t = i0 + lane;
         const bool mine = t < end;
@@ -344,10 +346,10 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
         const uint32_t nb = end - i0 < 64u ? end - i0 : 64u;
         uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)m_cnt, 0);
         const StarEntry* list = pool + (uint32_t)__builtin_amdgcn_readlane((int)m_off, 0);
-        StarEntry nxt = lane < cnt ? list[lane] : none;
+        uint4 nxt = fetch(list, lane < cnt ? lane : 0u);
         for (uint32_t u = 0; u < nb; ++u) {
             const uint32_t i = i0 + u;
-            const StarEntry cur = nxt;   // entries [0, 64) of node i
+            const uint4 cur = nxt;   // entries [0, 64) of node i
             const uint32_t nearest = (uint32_t)__builtin_amdgcn_readlane((int)m_near, (int)u);
             const double dn = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m_dn), (int)u), __builtin_amdgcn_readlane(__double2loint(m_dn), (int)u));
             const StarEntry* list_i = list;
@@ -355,20 +357,20 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
             if (u + 1 < nb) {   // the next node's first entries: requested now, used in the next trip
                 cnt = (uint32_t)__builtin_amdgcn_readlane((int)m_cnt, (int)(u + 1));
                 list = pool + (uint32_t)__builtin_amdgcn_readlane((int)m_off, (int)(u + 1));
-                nxt = lane < cnt ? list[lane] : none;
+                nxt = fetch(list, lane < cnt ? lane : 0u);
             }
             // 6. choose parent: cost(temp_node, q_near_node) first (:228), then the neighbours in ascending index with the running minimum
             const bool has0 = lane < cnt_i;
-            const double cj0 = has0 ? cost[cur.j] : 0.0;
+            const double cj0 = cost[has0 ? cur.x : 0u];
             const double c0 = unid(cost[nearest] + dn);
             double best_c = c0;
             uint32_t best_j = nearest;
             for (uint32_t e0 = 0; e0 < cnt_i; e0 += 64) {
                 const bool has = e0 + lane < cnt_i;
-                const StarEntry en = e0 == 0 ? cur : (has ? list_i[e0 + lane] : none);
-                const double cj = e0 == 0 ? cj0 : (has ? cost[en.j] : 0.0);
-                const double c = cj + en.d;                                   // cost(temp_node, neighbour), :104-113
-                const bool cand = has && (en.flags & 1u) != 0 && c < best_c;   // strict: an equal cost keeps the earlier choice
+                const uint4 en = e0 == 0 ? cur : fetch(list_i, has ? e0 + lane : 0u);
+                const double cj = e0 == 0 ? cj0 : cost[has ? en.x : 0u];
+                const double c = cj + __hiloint2double((int)en.w, (int)en.z);   // cost(temp_node, neighbour), :104-113
+                const bool cand = has && (en.y & 1u) != 0 && c < best_c;       // strict: an equal cost keeps the earlier choice
                 uint64_t m = __ballot(cand);
                 if (m == 0) continue;                        // (usual for a node whose nearest node is also its best parent)
                 if ((m & (m - 1)) != 0) {                    // several candidates: the cheapest, lowest index among equals (the list is ascending)
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
                 }
                 const int l = __ffsll((unsigned long long)m) - 1;
                 best_c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c), l), __builtin_amdgcn_readlane(__double2loint(c), l));
-                best_j = (uint32_t)__builtin_amdgcn_readlane((int)en.j, l);
+                best_j = (uint32_t)__builtin_amdgcn_readlane((int)en.x, l);
             }
             // 7. push: parent and cost of the new node (:244-250)
             if (lane == 0) { parent[i] = (int32_t)best_j; cost[i] = best_c; }
@@ -385,15 +387,15 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
             uint64_t rew_cnt = 0, rew_sum = 0;
             for (uint32_t e0 = 0; e0 < cnt_i; e0 += 64) {
                 const bool has = e0 + lane < cnt_i;
-                const StarEntry en = e0 == 0 ? cur : (has ? list_i[e0 + lane] : none);
-                const double cj = e0 == 0 ? cj0 : (has ? cost[en.j] : 0.0);
-                const double c2 = best_c + en.d;                              // cost(neighbour, new_node), :265
-                const bool rw = has && en.j != best_j && c2 < cj && (en.flags & 2u) != 0;
-                if (rw) { parent[en.j] = (int32_t)i; cost[en.j] = c2; }
+                const uint4 en = e0 == 0 ? cur : fetch(list_i, has ? e0 + lane : 0u);
+                const double cj = e0 == 0 ? cj0 : cost[has ? en.x : 0u];
+                const double c2 = best_c + __hiloint2double((int)en.w, (int)en.z);   // cost(neighbour, new_node), :265
+                const bool rw = has && en.x != best_j && c2 < cj && (en.y & 2u) != 0;
+                if (rw) { parent[en.x] = (int32_t)i; cost[en.x] = c2; }
                 uint64_t rm = __ballot(rw);
                 rew_cnt += (uint64_t)__popcll(rm);
                 for (; rm != 0; rm &= rm - 1)   // (a few lanes at most)
-                    rew_sum += (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)en.j, __ffsll((unsigned long long)rm) - 1);
+                    rew_sum += (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)en.x, __ffsll((unsigned long long)rm) - 1);
             }
             uint64_t w = fnv_mix(kFnvBasis, (uint64_t)best_j);
             w = fnv_mix(w, (uint64_t)__double_as_longlong(best_c));
