@@ -181,3 +181,36 @@ def test_prm_pair_search_streams_the_i_side_through_scalar_loads(prm_asm):
     # the i side never goes through LDS: the only LDS traffic is the staging buffer of the (rare) hits
     loop = body.split("sched_barrier")[1]
     assert "ds_read" not in loop.split("s_cbranch")[0]
+
+
+@pytest.fixture(scope="module")
+def star_wire_asm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("asm") / "rrt_star_wire.s")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "rrt_star_wire.hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_rrt_star_pair_search_keeps_its_shape(star_wire_asm):
+    """the neighbour search of the decoupled RRT* (DESIGN.md 10.1), star_pairs_kernel<3, count>: the wave-uniform fl32 rows
+    come through SCALAR loads (two s_load_dwordx16 per coordinate and trip of 32 nodes) although the kernel also stores
+    chunks and bumps a cursor -- as ordinary global loads the compiler turns them into per-lane vector loads and the pass
+    takes twice as long (measured: 26.7 ms against 14.4) --, the screen is packed binary32 (16 node pairs x 6 instructions per
+    trip), nothing spills, and eight waves fit a SIMD; the wiring kernel keeps its prefetched entries in registers"""
+    meta = _kernels(star_wire_asm)
+    names = [k for k in meta if "star_pairs_kernelILi3ELb0E" in k]
+    assert len(names) == 1
+    m = meta[names[0]]
+    assert m["vgpr_count"] <= 64 and m["vgpr_spill_count"] <= 1 and m["group_segment_fixed_size"] <= 16 * 1024, m
+    body = star_wire_asm.split(names[0] + ":")[1].split("s_endpgm")[0]
+    assert body.count("s_load_dwordx16") >= 6
+    assert "global_load_dwordx4" not in body          # the per-lane form the rows must not take
+    packed = body.count("v_pk_add_f32") + body.count("v_pk_mul_f32") + body.count("v_pk_fma_f32")
+    assert packed >= 96, packed
+    assert body.count("v_mul_f64") >= 3 and body.count("v_add_f64") >= 5   # the exact test: unfused binary64 sub / mul / add (fmas only inside sqrt)
+    wire = [k for k in meta if "star_wire_kernel" in k]
+    assert len(wire) == 1 and meta[wire[0]]["private_segment_fixed_size"] == 0
+    wbody = star_wire_asm.split(wire[0] + ":")[1].split("s_endpgm")[0]
+    for bad in ("scratch_", "flat_load", "ds_write", "ds_read"):   # entries in registers: no struct bounced through memory
+        assert bad not in wbody, bad
