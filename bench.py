@@ -25,6 +25,11 @@ size per iteration) is kept as `hbm_equivalent_GBps`; for the stream kernel it i
 the same workload on this host's cores -- and the run is only accepted if the GPU's per-problem node
 counts, iteration counts and checksums (every iteration folds nearest index, q_new bits and verdict) equal
 the oracle's on that sample, after the grow phase and after the frozen iterations.
+
+`secondary` / `secondary_f64`: the same steps through the stream kernel and the all-binary64 resident kernel (checksums must
+equal the main run's).  `secondary_rrt_star`: the RRT* row on the same scene and batch size, 1024 trees grown
+to 10,000 nodes; the checker grows problem 0 with the CPU oracle as well and refuses the line unless parents after rewiring,
+costs and checksum are identical.
 """
 import argparse
 import json
@@ -289,6 +294,39 @@ def main():
             except capi.OxhipError:
                 secondary_f64 = None
 
+    # the RRT* row (geometry by the same kernel as above, wiring by rrt_star_wire.hip), same scene, same batch
+    # size, search radius 1: 1024 trees grown to 10,000 nodes; problem 0 is grown by the CPU oracle too and its parents after
+    # rewiring, costs and checksum must be identical, or nothing is printed
+    secondary_star = None
+    if world == 1 and not args.no_secondary:
+        import numpy as np
+        star = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id, device=local_rank,
+                                    kernel=capi.KERNEL_AUTO, planner=capi.PLANNER_RRT_STAR, search_radius=1.0)
+        star.solve(10 ** 9)
+        st_t = star.last_timing()
+        st_c = star.counts()
+        assert (st_c["nodes"] == N_NODES).all()
+        verified = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle_py as orc
+            o = orc.OracleRRTStar(sc["dim"], sc["bounds"], sc["max_distance"], sc["goal_bias"], 1.0, sc["lvs_fraction"], N_NODES, False,
+                                  seed, first_id)
+            o.set_spheres(*sc["spheres"])
+            o.setup(sc["start"], sc["goal_centre"], sc["goal_radius"])
+            o.solve(10 ** 9)
+            _, gp = star.tree(0)
+            _, op = o.tree()
+            verified = bool(np.array_equal(gp, op) and np.array_equal(star.costs(0).view(np.uint64), o.costs().view(np.uint64))
+                            and int(st_c["checksum"][0]) == o.checksum and int(st_c["iterations"][0]) == o.iterations)
+            if not verified:
+                raise SystemExit("bench.py: RRT* (decoupled design) != oracle on problem %d: refusing to report" % first_id)
+        secondary_star = {"planner": "RRT* (rrt_star.rs), search radius 1.0, %d trees grown 1 -> %d nodes" % (P, N_NODES),
+                          "design": "decoupled: rrt_lanes.hip + rrt_star_wire.hip" if st_t["kernel"] == capi.KERNEL_LANES else "one kernel: rrt_star.hip",
+                          "iterations": int(st_c["iterations"].sum()), "kernel_ms": st_t["kernel_ms"],
+                          "iterations_per_s": float(st_c["iterations"].sum()) / (st_t["kernel_ms"] * 1e-3),
+                          "problem0_parents_costs_checksum_equal_oracle": verified}
+        star.close()
+
     # RCCL all-gather over xGMI (nccl backend): throughput report only, no data-path collective
     allst = sharding.gather_stats([dt, float(iters_timed), kernel_ms, float(launches), float(grow_iters), grow_s,
                                    grow_t["kernel_ms"]], device="cuda")
@@ -351,6 +389,8 @@ def main():
             out["secondary"] = secondary_stream
         if secondary_f64 is not None:
             out["secondary_f64"] = secondary_f64
+        if secondary_star is not None:
+            out["secondary_rrt_star"] = secondary_star
         if not args.no_cpu_baseline and world == 1:  # the contract: rank 0, N = 1 only
             threads = min(os.cpu_count() or 1, 16, P)
             frozen = args.iters * (args.steps + args.warmup)
