@@ -191,6 +191,12 @@ __device__ __forceinline__ float f32_up(double x) {   // a binary32 value >= x (
     return t + fabsf(t) * 0x1p-22f + 1e-37f;
 }
 
+// bits <- 2 bits + [!(sp > thr)]: a screen verdict shifted into a lane's bit string in two instructions (compare into vcc,
+// add-with-carry of the string to itself); NaN counts as "look".  After eight calls verdict t sits at bit 7 - t.
+__device__ __forceinline__ void screen_bit(uint32_t& bits, float sp, float thr) {
+    asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(sp), "v"(thr) : "vcc");
+}
+__device__ __forceinline__ uint32_t rev8(uint32_t bits) { return __brev(bits) >> 24; }   // verdict t back at bit t
 __device__ __forceinline__ uint64_t below_mask(uint32_t lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ uint64_t first_n_mask(uint32_t n) { return n >= 64u ? ~0ull : ((1ull << n) - 1ull); }
 
@@ -846,16 +852,22 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             const uint32_t lo = wave_min_u32(act ? bmin : 0xFFFFFFFFu);
             // (eight ring nodes per trip: their LDS reads -- wave-uniform addresses -- are issued together)
             for (uint32_t i0 = lo; i0 < n; i0 += 8) {
-                uint32_t lookm = 0;
+                // which of the trip's eight nodes concern this lane at all: i0 + t in [bmin, n) -- one mask per trip instead of
+                // two compares per node
+                const uint32_t t_hi = n - i0 < 8u ? n - i0 : 8u;
+                const uint32_t t_lo = bmin > i0 ? (bmin - i0 < 8u ? bmin - i0 : 8u) : 0u;
+                const uint32_t valid = act ? (((1u << t_hi) - 1u) & ~((1u << t_lo) - 1u)) : 0u;
+                uint32_t bits = 0;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const uint32_t i = i0 + (uint32_t)t;
-                    const float* nf = sh.newn32[i & (kNRing - 1)];   // (slots past n hold stale nodes: masked below)
+                    const float* nf = sh.newn32[i & (kNRing - 1)];   // (slots past n hold stale nodes: masked by `valid`)
                     float sp = nf[D];
 #pragma unroll
                     for (int k = 0; k < D; ++k) sp = __builtin_fmaf(nf[k], Qf[k], sp);
-                    lookm |= (act && i >= bmin && i < n && !(sp > thr)) ? (1u << t) : 0u;   // (NaN: look)
+                    screen_bit(bits, sp, thr);   // (NaN: look)
                 }
+                const uint32_t lookm = rev8(bits) & valid;
                 if (STAMP) ++n_fold_trips;
                 if (__ballot(lookm != 0) != 0) {
 #pragma unroll
@@ -966,15 +978,16 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             } else {
             // Full rounds: every lane walks the 64 spheres (eight LDS reads -- wave-uniform, broadcast -- per trip)
             for (uint32_t o0 = 0; o0 < ns64; o0 += 8) {
-                uint32_t bits = 0;
+                uint32_t b8 = 0;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const float* of = sh.obs32[o0 + t];
                     float sp = of[D];
 #pragma unroll
                     for (int k = 0; k < D; ++k) sp = __builtin_fmaf(of[k], Qm[k], sp);
-                    bits |= !(sp + mm > sh.obs32_thr[o0 + t]) ? (1u << t) : 0u;   // (NaN / inf threshold: maybe; -1: no sphere)
+                    screen_bit(b8, sp + mm, sh.obs32_thr[o0 + t]);   // !(sp + mm > thr)  (NaN / inf threshold: maybe; -1: no sphere)
                 }
+                const uint32_t bits = rev8(b8);
                 if (o0 < 32) maybe_lo |= bits << o0; else maybe_hi |= bits << (o0 - 32);
             }
             }
@@ -1099,15 +1112,20 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             const uint32_t n_new = (uint32_t)__popcll(newm);
             for (uint32_t t0 = 0; t0 < n_new; t0 += 8) {
                 // lanes in front of the first inserting lane of this trip are out of reach; so is everything behind the cut
-                uint32_t lookm = 0;
+                // the staged nodes of this trip that lie in front of this lane: t < min(rank, n_new) - t0, for lanes inside the cut
+                const uint32_t ahead = rank < n_new ? rank : n_new;
+                const uint32_t t_hi = ahead > t0 ? (ahead - t0 < 8u ? ahead - t0 : 8u) : 0u;
+                const uint32_t valid = (act && lane < cut) ? ((1u << t_hi) - 1u) : 0u;
+                uint32_t bits = 0;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const float* nf = sh.newn32[(n + t0 + (uint32_t)t) & (kNRing - 1)];
                     float sp = nf[D];
 #pragma unroll
                     for (int k = 0; k < D; ++k) sp = __builtin_fmaf(nf[k], Qf[k], sp);
-                    lookm |= (act && rank > t0 + (uint32_t)t && t0 + (uint32_t)t < n_new && lane < cut && !(sp > thr_c)) ? (1u << t) : 0u;
+                    screen_bit(bits, sp, thr_c);
                 }
+                const uint32_t lookm = rev8(bits) & valid;
                 if (STAMP) ++n_conf_trips;
                 if (__ballot(lookm != 0) != 0) {
 #pragma unroll
