@@ -75,6 +75,9 @@ constexpr uint32_t kDepthGrow = OXHIP_DEPTH_GROW;                 // queries sam
 #ifndef OXHIP_WANT_DIV_GROW
 #define OXHIP_WANT_DIV_GROW 8   // while inserts are on the resolver starts a round when 1/this of the window is published
 #endif
+#ifndef OXHIP_LANES_FOLD
+#define OXHIP_LANES_FOLD 8
+#endif
 #ifndef OXHIP_LANES_TRIP
 #define OXHIP_LANES_TRIP(DIM) 2   // (R^5 / R^6 with one block per trip -- 32 registers less in the resolver, which spills there -- was measured: see DESIGN.md 5.5)
 #endif
@@ -675,6 +678,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 
     typedef double ldouble4 __attribute__((ext_vector_type(4)));
     constexpr int kTrip = OXHIP_LANES_TRIP(DIM);   // candidate blocks fetched per memory round trip
+    constexpr int kFold = OXHIP_LANES_FOLD;       // ring nodes screened per trip of the fold
     // the last whole-tree answer: valid while the tree has not grown (see the exact path)
     uint32_t memo_n = 0xFFFFFFFFu, memo_idx = kNoNode;
     double memo_g = 0.0, memo_q[D];
@@ -851,15 +855,15 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             float thr = (mg.usable && pd.b1 < 1e300) ? f32_up(pd.b1 * (1.0 + 0x1p-19) - bb + mg.e2) : __builtin_inff();
             const uint32_t lo = wave_min_u32(act ? bmin : 0xFFFFFFFFu);
             // (eight ring nodes per trip: their LDS reads -- wave-uniform addresses -- are issued together)
-            for (uint32_t i0 = lo; i0 < n; i0 += 8) {
-                // which of the trip's eight nodes concern this lane at all: i0 + t in [bmin, n) -- one mask per trip instead of
+            for (uint32_t i0 = lo; i0 < n; i0 += kFold) {
+                // which of the trip's nodes concern this lane at all: i0 + t in [bmin, n) -- one mask per trip instead of
                 // two compares per node
-                const uint32_t t_hi = n - i0 < 8u ? n - i0 : 8u;
-                const uint32_t t_lo = bmin > i0 ? (bmin - i0 < 8u ? bmin - i0 : 8u) : 0u;
+                const uint32_t t_hi = n - i0 < (uint32_t)kFold ? n - i0 : (uint32_t)kFold;
+                const uint32_t t_lo = bmin > i0 ? (bmin - i0 < (uint32_t)kFold ? bmin - i0 : (uint32_t)kFold) : 0u;
                 const uint32_t valid = act ? (((1u << t_hi) - 1u) & ~((1u << t_lo) - 1u)) : 0u;
                 uint32_t bits = 0;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+                for (int t = 0; t < kFold; ++t) {
                     const uint32_t i = i0 + (uint32_t)t;
                     const float* nf = sh.newn32[i & (kNRing - 1)];   // (slots past n hold stale nodes: masked by `valid`)
                     float sp = nf[D];
@@ -867,11 +871,11 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                     for (int k = 0; k < D; ++k) sp = __builtin_fmaf(nf[k], Qf[k], sp);
                     screen_bit(bits, sp, thr);   // (NaN: look)
                 }
-                const uint32_t lookm = rev8(bits) & valid;
+                const uint32_t lookm = (__brev(bits) >> (32 - kFold)) & valid;
                 if (STAMP) ++n_fold_trips;
                 if (__ballot(lookm != 0) != 0) {
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) {
+                    for (int t = 0; t < kFold; ++t) {
                         if (__ballot((lookm >> t) & 1u) != 0) {
                             if (STAMP) ++n_fold_exact;
                             const uint32_t i = i0 + (uint32_t)t;
