@@ -282,6 +282,28 @@ def test_rrt_config2_golden_and_oracle_batch(golden, kernel):
     gpu.close()
 
 
+@pytest.mark.parametrize("kernel", [capi.KERNEL_LANES, capi.KERNEL_AUTO], ids=lambda k: KNAME[k])
+@pytest.mark.parametrize("dim,max_nodes", [(3, 15000), (2, 20000), (2, 11500)])
+def test_rrt_large_row_instantiations(kernel, dim, max_nodes):
+    """trees beyond 11,264 nodes run the lane-per-query kernel's 32-row (R^3, up to 16,384 nodes) and 40-row (R^2, up to
+    20,480) instantiations: grown to capacity, then frozen iterations at full size, against the oracle"""
+    sc = scenarios.config2() if dim == 3 else scenarios.config1()
+    P = 3
+    gpu = _gpu_for(sc, P, max_nodes, False, 11, 40, kernel)
+    gpu.solve(6000)             # resume across the instantiation's whole range
+    gpu.solve(10 ** 7)
+    gpu.solve(700, freeze=True)
+    c = gpu.counts()
+    assert (c["nodes"] == max_nodes).all()
+    assert gpu.last_timing()["kernel"] == capi.KERNEL_LANES
+    planners = [_oracle_for(sc, 11, 40 + p, max_nodes, False) for p in range(P)]
+    orc.solve_many(planners, 10 ** 7, threads=3)
+    orc.solve_many(planners, 700, freeze=True, threads=3)
+    for p in range(P):
+        _assert_same_problem(gpu, p, planners[p], c)
+    gpu.close()
+
+
 @pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
 def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
     """dims 1..6, spheres+boxes mixed, goal_bias 0 / 1 / 0.5, more obstacles than one wave."""

@@ -234,3 +234,17 @@ def test_rrt_star_full_size_config2(star_golden, star_design):
         assert par[0] == -1 and cost[0] == 0.0
         assert (par[1:] >= 0).all() and (par[1:] < 10000).all()
         assert (cost[1:] > cost[par[1:]]).all() or (cost[1:] >= cost[par[1:]]).all()   # cost = parent's cost + a distance
+
+
+def test_rrt_star_large_row_instantiation(star_golden, star_design):
+    """a 13,000-node RRT* tree: the decoupled design's geometry then comes from the lane-per-query kernel's 32-row instantiation"""
+    P = dict(star_golden["config2"]["params"], search_radius=0.6, max_nodes=13000)
+    g = make_gpu(P, 2, 5, 9, stop=False)
+    g.solve(10 ** 9)
+    c = g.counts()
+    assert (c["nodes"] == 13000).all()
+    if star_design == "decoupled":
+        assert g.last_timing()["kernel"] == capi.KERNEL_LANES
+    o = make_oracle(P, 5, 10, stop=False)
+    o.solve(10 ** 9)
+    assert_same(g, 1, o, c)
