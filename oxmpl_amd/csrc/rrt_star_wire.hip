@@ -286,6 +286,31 @@ __global__ __launch_bounds__(256) void star_edges_kernel(DevParams p) {
                 if (!(dist2<DIM>(c, mid, DIM) > lim)) mask |= 1ull << jj;   // NaN / inf radii stay in
             }
             if (mask == 0) continue;
+            // second, tighter filter for the few spheres the midpoint test left: every interpolated state of either motion is a
+            // point of the segment [a, b] up to a few ulps, so a sphere whose distance to the SEGMENT exceeds r (+ the same kind
+            // of margin) cannot be hit either.  (A computed closest point is still a point near the segment: its distance can
+            // only overestimate the minimum by the square of the parameter's rounding error -- far below the margin.)
+            {
+                const double inv_len2 = 1.0 / en.d;   // (nsteps > 1: a != b)
+                const double h2 = 1e-6 * dist + p.filt_abs;
+                for (uint64_t m = mask; m != 0; m &= m - 1) {
+                    const uint32_t o = (uint32_t)(__ffsll((unsigned long long)m) - 1);
+                    double dot = 0.0;
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) dot += (sc[k][o] - a[k]) * (b[k] - a[k]);
+                    double ts = dot * inv_len2;
+                    ts = ts < 0.0 ? 0.0 : (ts > 1.0 ? 1.0 : ts);   // (NaN stays NaN: the sphere stays in)
+                    double d2s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) {
+                        const double e = sc[k][o] - (a[k] + ts * (b[k] - a[k]));
+                        d2s += e * e;
+                    }
+                    const double rr = srad[o] + h2;
+                    if (d2s > rr * rr * (1.0 + 1e-9)) mask &= ~(1ull << o);
+                }
+            }
+            if (mask == 0) continue;
             for (uint32_t step = 1; step <= nsteps && (ab || ba); ++step) {
                 const double t = (double)step / dn;
                 double s1[DIM], s2[DIM];
