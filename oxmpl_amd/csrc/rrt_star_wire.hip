@@ -120,8 +120,11 @@ __global__ __launch_bounds__(kPairThreads, 8) void star_pairs_kernel(DevParams p
                 const sw_f32x2 e = cj - xf[k];
                 s = k == 0 ? e * e : __builtin_elementwise_fma(e, e, s);
             }
-            bits |= (s[0] <= thr32 ? (1u << t) : 0u) | (s[1] <= thr32 ? (2u << t) : 0u);
+            // two verdicts shifted into the lane's bit string: compare into vcc, add-with-carry of the string to itself
+            asm("v_cmp_le_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\tv_cmp_le_f32 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                : "+v"(bits) : "v"(s[0]), "v"(s[1]), "v"(thr32) : "vcc");
         }
+        if (screen) bits = __brev(bits);   // verdict t back at bit t
         // only nodes before this lane's own count (j < i)
         const uint32_t lim = (act && i > j0) ? (i - j0 >= 32u ? 0xFFFFFFFFu : ((1u << (i - j0)) - 1u)) : 0u;
         bits &= lim;
