@@ -49,6 +49,8 @@ struct oxhip_rrt_batch {
     DevBuf<StarChunk> chunks;
     DevBuf<uint32_t> chunk_cursor;
     bool star_wired = false;        // RRT*: geometry by rrt_lanes.hip + the wiring kernels (else rrt_star.hip)
+    hipStream_t stream2 = nullptr;  // RRT*, decoupled: the wiring of a segment runs here while the next segment's pairs are checked on `stream`
+    hipEvent_t ev_seg[8] = {}, ev_join = nullptr;
     DevBuf<float> tree32;           // stream / RRT* kernels: fl32 shadow of the tree
     DevBuf<uint32_t> shadow_state;  // [P][2]
     DevBuf<uint32_t> nb_idx;
@@ -210,6 +212,9 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             }
             if (share < cap) share = cap;   // a single list is at most cap entries long: every round wires at least one node
             dp.pool_share = (uint32_t)share;
+            chk(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+            for (auto& ev : b->ev_seg) chk(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            chk(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
             chk(b->pool.alloc((size_t)P * share + 64));   // (+ padding: masked lanes of the wiring kernel read one entry past an empty list)
             dp.chunk_share = (uint32_t)(share / 32 + cap);   // enough for any set of lists that fits the pool segment (one partial chunk per node)
             chk(b->chunks.alloc((size_t)P * dp.chunk_share));
@@ -286,6 +291,9 @@ int32_t oxhip_rrt_batch_destroy(oxhip_rrt_batch* b) {
     if (!b) return OXHIP_OK;
     (void)hipSetDevice(b->cfg.device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
+    for (auto ev : b->ev_seg) if (ev) (void)hipEventDestroy(ev);
+    if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -549,8 +557,20 @@ static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
         }
         if (one_pass) launch_star_compact(b->dp, max_chunks, b->stream);
         else launch_star_fill(b->dp, max_take, b->stream);
-        launch_star_edges(b->dp, max_total, b->stream);
-        launch_star_wire(b->dp, b->stream);
+        // The pairs are checked segment by segment (of the entries) and a segment's nodes -- those whose lists end inside it --
+        // are wired on a second stream meanwhile: the wiring kernel is one latency-bound wave per problem and shares the
+        // chip with the next segment's throughput-bound edge kernel at almost no cost to either
+        const uint32_t segs = (max_total >= 64u * 1024u && std::getenv("OXHIP_STAR_ONE_SEGMENT") == nullptr) ? 8u : 1u;
+        for (uint32_t sgi = 0; sgi < segs; ++sgi) {
+            b->dp.seg_index = sgi;
+            b->dp.seg_count = segs;
+            launch_star_edges(b->dp, max_total / segs + 2u, b->stream);
+            HIP_TRY(hipEventRecord(b->ev_seg[sgi], b->stream));
+            HIP_TRY(hipStreamWaitEvent(b->stream2, b->ev_seg[sgi], 0));
+            launch_star_wire(b->dp, b->stream2);
+        }
+        HIP_TRY(hipEventRecord(b->ev_join, b->stream2));
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_join, 0));
         HIP_TRY(hipGetLastError());
     }
 }

@@ -98,6 +98,7 @@ struct DevParams {
     struct StarChunk* chunks; // [P][chunk_share]
     uint32_t* chunk_cursor;   // [P] chunks handed out this round (may run past chunk_share: then the round takes the two-pass path)
     uint32_t chunk_share;
+    uint32_t seg_index, seg_count;   // star_edges / star_wire: this launch's segment of the round (entries resp. the nodes whose lists end in them)
     // PRM only (prm_kernels.hip): the midpoint filter's inputs for motions of any length
     const double* sph_r;    // [n_spheres] radii as given
     double filt_abs;        // 1e-9 * largest coordinate magnitude in play (absolute rounding margin)

@@ -236,10 +236,14 @@ template <int DIM>
 __global__ __launch_bounds__(256) void star_edges_kernel(DevParams p) {
     __shared__ double sc[DIM][64], srad[64], sthr[64];
     const uint32_t prob = blockIdx.y, tid = threadIdx.x;
+    // the launch covers segment seg_index of seg_count of the problem's entries (the wiring of a segment runs on a second
+    // stream while the next segment's pairs are checked here)
     const uint32_t total = p.nbr_total[prob];
-    if (blockIdx.x * 256u >= total) return;
-    const uint32_t e = blockIdx.x * 256u + tid;
-    const bool act = e < total;
+    const uint32_t e_lo = (uint32_t)((uint64_t)total * p.seg_index / p.seg_count);
+    const uint32_t e_hi = (uint32_t)((uint64_t)total * (p.seg_index + 1u) / p.seg_count);
+    if (e_lo + blockIdx.x * 256u >= e_hi) return;
+    const uint32_t e = e_lo + blockIdx.x * 256u + tid;
+    const bool act = e < e_hi;
     const size_t cap = p.cap;
     const double* __restrict__ tree = p.tree + (size_t)prob * DIM * cap;
     StarEntry* ent = p.pool + (size_t)prob * p.pool_share + (act ? e : 0u);
@@ -363,10 +367,24 @@ __global__ __launch_bounds__(256) void star_edges_kernel(DevParams p) {
 // them (vector memory operations of a wave execute in order; the stores write through the CU's own L1).
 __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
     const uint32_t prob = blockIdx.x, lane = threadIdx.x;
-    const uint32_t w0 = p.wired[prob], take = p.nbr_take[prob];
+    const uint32_t wired0 = p.wired[prob], take = p.nbr_take[prob];
     if (take == 0) return;
-    const uint32_t end = w0 + take;
     const size_t cap = p.cap, base = (size_t)prob * cap;
+    // segment seg_index of seg_count: the nodes whose lists END inside the entries checked so far -- lists are contiguous
+    // and ascending, so that is a prefix of the round's nodes, found by bisection on the lists' ends
+    const uint32_t total = p.nbr_total[prob];
+    auto nodes_within = [&](uint32_t e_end) {   // how many of the round's nodes have their whole list below entry e_end
+        uint32_t lo = 0, hi = take;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (p.nbr_off[base + wired0 + mid] + p.nbr_cnt[base + wired0 + mid] <= e_end) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const bool last_seg = p.seg_index + 1u == p.seg_count;
+    const uint32_t n_lo = p.seg_index == 0 ? 0u : nodes_within((uint32_t)((uint64_t)total * p.seg_index / p.seg_count));
+    const uint32_t n_hi = last_seg ? take : nodes_within((uint32_t)((uint64_t)total * (p.seg_index + 1u) / p.seg_count));
+    const uint32_t w0 = wired0 + n_lo, end = wired0 + n_hi;
     double* cost = p.cost + base;
     int32_t* parent = p.parent + base;
     const StarEntry* pool = p.pool + (size_t)prob * p.pool_share;
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
     }
     if (lane == 0) {
         p.wire_chk[prob] = W;
-        p.wired[prob] = end;
+        if (last_seg) p.wired[prob] = end;   // (the cursor moves once the whole round is wired: the edge launches read it)
     }
 }
 
