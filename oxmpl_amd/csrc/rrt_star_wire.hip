@@ -20,6 +20,9 @@
 //                   neighbour but the parent whose cost drops and whose motion is valid (:253-282; each decision depends on
 //                   that neighbour's own cost only).  Costs are read and written in order, so rewires of earlier nodes are
 //                   seen by later ones exactly as in the reference.
+// Stages 2 and 3 run segment by segment (eighths of the round's pairs): while star_edges checks segment s + 1 on the batch's
+// stream, star_wire wires the nodes whose lists end inside segment s on a second stream -- one latency-bound wave per problem
+// next to a throughput-bound kernel (oxhip_api.hip, wire_new_nodes).
 // Everything that enters a result is binary64 in the reference's evaluation order.
 #include "oxhip_internal.hpp"
 #include "rrt_device.hpp"
