@@ -44,17 +44,15 @@ if ROOT not in sys.path:
 N_NODES = 10000
 BYTES_PER_ITER = N_NODES * 3 * 8          # B(n) = n * d * 8
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
-KNAME = {1: "stream", 2: "resident", 3: "pruned", 4: "resident_f32", 5: "lanes"}
+KNAME = {1: "stream", 2: "resident", 5: "lanes"}
 ROWS_PER_ITERATION = 10240 // 64          # register rows (64 nodes each) one query is screened against
 CUS = 256
 
 
 def valu_peak(kname):
     """Measured VALU ceiling of the kernel's scan on this chip, iterations/s, and where it comes from.
-    resident_f32: profiles/r2_valu_peak.json, the bare screen loop (3 packed f32 ops + v_and_or_b32 + v_med3_u32 +
-    v_min_u32 per register row and query; 22 rows, two waves per SIMD as in the kernel) in (row, query) pairs per second,
-    divided by the 160 rows of a 10,240-slot tree.  resident (binary64 scanners): tools/scan_bench.hip, 1.0 us per
-    10k-node scan per CU (profiles/r1_resident)."""
+    lanes: the bare screen loop of the kernel in (row, query) pairs per second, divided by the 160 rows of a 10,240-slot tree.
+    resident (binary64 scanners): tools/scan_bench.hip, 1.0 us per 10k-node scan per CU (profiles/r1_resident)."""
     if kname == "lanes":
         # the dot-product screen: D packed fused multiply-adds per PAIR of 64-node register rows and query + one v_min3_f32
         # (2.0 instructions per row and query in R^3), 24 rows, two waves per SIMD as in the kernel; a 10,000-node tree occupies
@@ -69,17 +67,6 @@ def valu_peak(kname):
         except (OSError, KeyError, ValueError):
             pass
         return None, "profiles/r2_valu_peak.json has no dot_screen_min3 entry"
-    if kname == "resident_f32":
-        try:
-            with open(os.path.join(ROOT, "profiles", "r2_valu_peak.json")) as f:
-                d = json.load(f)
-            for e in d["screen"]:
-                if e["mode"] == 0 and e["dim"] == 3 and e["rows"] == 22 and e["waves_per_simd"] == 2:
-                    return e["row_queries_per_s_chip"] / ROWS_PER_ITERATION, \
-                        "profiles/r2_valu_peak.json: screen mode 0, 22 rows, 2 waves/SIMD, / 160 rows per iteration"
-        except (OSError, KeyError, ValueError):
-            pass
-        return None, "profiles/r2_valu_peak.json missing"
     if kname == "resident":
         return 258.0e6, "tools/scan_bench.hip: 1.0 us per 10k-node binary64 scan per CU x 256 CUs"
     return None, None
@@ -132,30 +119,72 @@ def oracle_planners(sc, seed, first_id, count):
     return orc, planners
 
 
-def cpu_baseline_and_check(sc, seed, first_id, threads, frozen_iters, gpu_after_grow, gpu_after_frozen):
-    """Oracle (kind 'port') on `threads` host cores: `threads` problems grown to 10k nodes (untimed), then `frozen_iters`
-    frozen iterations each (timed) -- the same per-iteration work as the GPU step, and the SAME iterations the GPU ran
-    for those problems: node counts, iteration counts and checksums must agree at both points, or the run is refused."""
-    orc, planners = oracle_planners(sc, seed, first_id, threads)
+def host_cores():
+    """(cores the machine has, cores this process may use): os.cpu_count(), then the scheduler affinity mask and the cgroup v2 /
+    v1 CPU quota, whichever is smaller -- a container that is given 16 of 256 cores reports (256, 16)."""
+    total = os.cpu_count() or 1
+    usable = total
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            with open(path) as f:
+                txt = f.read().strip()
+            if parse is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    quota, period = txt, f.read().strip()
+            else:
+                quota, period = parse(txt)
+            if quota not in ("max", "-1") and int(quota) > 0:
+                usable = min(usable, max(1, -(-int(quota) // int(period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return total, max(1, usable)
+
+
+def oracle_check(sc, seed, first_id, count, threads, frozen_iters, gpu_after_grow, gpu_after_frozen, offset=0):
+    """`count` problems of this rank's shard (local indices offset .. offset + count - 1) through the oracle: grown to 10k nodes,
+    then `frozen_iters` frozen iterations -- node counts, iteration counts and per-iteration checksums must equal the GPU's at
+    both points, or the run is refused.  Returns (planners, seconds of the frozen leg)."""
+    orc, planners = oracle_planners(sc, seed, first_id + offset, count)
     orc.solve_many(planners, 10 ** 7, threads=threads)
-    for p, o in enumerate(planners):
+    for i, o in enumerate(planners):
+        p = offset + i
         if not (o.num_nodes == N_NODES == int(gpu_after_grow["nodes"][p]) and o.iterations == int(gpu_after_grow["iterations"][p])
                 and o.checksum == int(gpu_after_grow["checksum"][p])):
-            raise SystemExit("bench.py: GPU != oracle after the grow phase, problem %d: refusing to report a number" % p)
+            raise SystemExit("bench.py: GPU != oracle after the grow phase, problem id %d: refusing to report a number" % (first_id + p))
     t0 = time.perf_counter()
     orc.solve_many(planners, frozen_iters, freeze=True, threads=threads)
     dt = time.perf_counter() - t0
-    for p, o in enumerate(planners):
+    for i, o in enumerate(planners):
+        p = offset + i
         if not (o.iterations == int(gpu_after_frozen["iterations"][p]) and o.checksum == int(gpu_after_frozen["checksum"][p])
                 and o.num_nodes == int(gpu_after_frozen["nodes"][p])):
-            raise SystemExit("bench.py: GPU != oracle after %d frozen iterations, problem %d: refusing to report a number"
-                             % (frozen_iters, p))
-    # the reference is single-threaded per planner: one problem on one core (SURVEY.md 8(d))
+            raise SystemExit("bench.py: GPU != oracle after %d frozen iterations, problem id %d: refusing to report a number"
+                             % (frozen_iters, first_id + p))
+    return orc, planners, dt
+
+
+def cpu_baseline_and_check(sc, seed, first_id, P, frozen_iters, gpu_after_grow, gpu_after_frozen):
+    """Oracle (kind 'port') on ALL the cores this process may use: one problem per thread -- the reference is
+    single-threaded per planner -- grown to 10k nodes (untimed), then `frozen_iters` frozen iterations each (timed): the same
+    per-iteration work as the GPU step, and the SAME iterations the GPU ran for those problems (checked, see oracle_check)."""
+    total, usable = host_cores()
+    threads = min(usable, P)
+    orc, planners, dt = oracle_check(sc, seed, first_id, threads, threads, frozen_iters, gpu_after_grow, gpu_after_frozen)
+    # one problem on one core
     n1 = min(frozen_iters, 60000)
     t1 = time.perf_counter()
     orc.solve_many(planners[:1], n1, freeze=True, threads=1)
     dt1 = time.perf_counter() - t1
     return dict(value=threads * frozen_iters / dt, unit="iterations/s", cores=threads, kind="port", value_1core=n1 / dt1,
+                host_cores=total, usable_cores=usable, threads=threads,
+                cores_note="host_cores = os.cpu_count(); usable_cores = min(that, scheduler affinity, cgroup CPU quota); one oracle "
+                           "planner per usable core",
                 sample="%d problems x %d frozen iterations at n=10000 on %d threads (oracle/rrt_oracle.c, C restatement "
                        "of rrt.rs:170-225); the GPU ran the same iterations of the same problems" % (threads, frozen_iters, threads),
                 verified="GPU node counts, iteration counts and per-iteration checksums == oracle for problems %d..%d after the "
@@ -173,6 +202,12 @@ def main():
     ap.add_argument("--iters", type=int, default=4096, help="RRT iterations per problem per step")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 stream, 2 resident (binary64 scanners), 4 resident + binary32 screen (lane groups), "
                                                           "5 resident + binary32 dot-product screen, lane-per-query resolver")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend for the barriers and the one all-gather (nccl = RCCL over xGMI; gloo: rehearsals "
+                         "of the N > 1 branch on a box with fewer GPUs than ranks)")
+    ap.add_argument("--device-map", default="", help="comma-separated HIP device per local rank (default: local rank r -> device r); "
+                                                     "'0,0' runs two ranks on GPU 0")
+    ap.add_argument("--rank-check", type=int, default=2, help="N > 1: problems of its own shard every rank checks against the oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary measurements (stream kernel, all-binary64 resident kernel)")
     args = ap.parse_args()
@@ -184,12 +219,22 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
 
+    device = local_rank
+    if args.device_map:
+        dm = [int(v) for v in args.device_map.split(",")]
+        if local_rank >= len(dm):
+            raise SystemExit("--device-map names %d devices but local rank %d exists" % (len(dm), local_rank))
+        device = dm[local_rank]
+
     import torch  # plumbing only: device sync + torch.distributed (RCCL) barriers / gather
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     def barrier():
         if world > 1:
@@ -206,10 +251,10 @@ def main():
     P, seed = args.problems, 42
     first_id, _ = sharding.problem_range(rank, P)
     gpu = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id,
-                               device=local_rank, kernel=args.kernel)
+                               device=device, kernel=args.kernel)
     # one tiny launch first: the first launch of a process pays for loading the code object (milliseconds, inside the
     # HIP-event bracket of whatever runs first); the "grow" figure below is the second launch of the process
-    warm = scenarios.make_batch(sc, 4, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id, device=local_rank,
+    warm = scenarios.make_batch(sc, 4, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id, device=device,
                                 kernel=args.kernel)
     warm.solve(256)
     warm.close()
@@ -228,7 +273,7 @@ def main():
     snap = None   # (frozen iterations per problem, counters) at a point the CPU check can afford to reach
     for w in range(args.warmup):
         gpu.solve(args.iters, freeze=True)
-        if rank == 0 and world == 1 and not args.no_cpu_baseline and (w + 1) * args.iters <= 400000:
+        if not args.no_cpu_baseline and (w + 1) * args.iters <= 400000:
             snap = ((w + 1) * args.iters, gpu.counts())   # untimed: warm-up
     barrier()
     t0 = time.perf_counter()
@@ -250,7 +295,7 @@ def main():
     def side_run(kernel, steps=2):
         """the same workload through another kernel kind (rank 0, N = 1 only)"""
         g2 = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id,
-                                  device=local_rank, kernel=kernel)
+                                  device=device, kernel=kernel)
         g2.solve(10 ** 7)
         total = args.steps + args.warmup          # as many frozen steps as the main run, the last `steps` of them timed
         steps = min(steps, total)
@@ -270,7 +315,7 @@ def main():
     secondary_stream = secondary_f64 = None
     copy_gbs = None
     if world == 1 and not args.no_secondary:
-        copy_gbs = copy_peak_gbs(torch, torch.device("cuda", local_rank))
+        copy_gbs = copy_peak_gbs(torch, torch.device("cuda", device))
         if kname != "stream":
             ms, same = side_run(capi.KERNEL_STREAM)
             ach = P * args.iters * BYTES_PER_ITER / (ms * 1e-3) / 1e9
@@ -300,7 +345,7 @@ def main():
     secondary_star = None
     if world == 1 and not args.no_secondary:
         import numpy as np
-        star = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id, device=local_rank,
+        star = scenarios.make_batch(sc, P, N_NODES, stop_at_goal=False, seed=seed, first_problem_id=first_id, device=device,
                                     kernel=capi.KERNEL_AUTO, planner=capi.PLANNER_RRT_STAR, search_radius=1.0)
         star.solve(10 ** 9)
         st_t = star.last_timing()
@@ -327,9 +372,30 @@ def main():
                           "problem0_parents_costs_checksum_equal_oracle": verified}
         star.close()
 
-    # RCCL all-gather over xGMI (nccl backend): throughput report only, no data-path collective
+    def check_point():
+        """(frozen iterations per problem, GPU counters there): the whole frozen run when the CPU can afford it, else the last
+        warm-up boundary"""
+        frozen = args.iters * (args.steps + args.warmup)
+        if frozen <= 400000:
+            return frozen, c2
+        if snap is not None:
+            return snap
+        raise SystemExit("bench.py: %d frozen iterations per problem are too many for the CPU check and there is no "
+                         "warm-up boundary to compare at; use --warmup >= 1 or --no-cpu-baseline" % frozen)
+
+    # N > 1: every rank checks the LAST `rank_check` problems of its own shard against the oracle (same rule as the N = 1 run:
+    # no agreement, no line) -- after the timed region, outside every bracket
+    checked = 0
+    if world > 1 and not args.no_cpu_baseline and args.rank_check > 0:
+        k = min(args.rank_check, P)
+        point = check_point()
+        oracle_check(sc, seed, first_id, k, min(k, host_cores()[1]), point[0], c, point[1], offset=P - k)
+        checked = k
+
+    # one all-gather (RCCL over xGMI with the nccl backend): throughput report only, no data-path collective
     allst = sharding.gather_stats([dt, float(iters_timed), kernel_ms, float(launches), float(grow_iters), grow_s,
-                                   grow_t["kernel_ms"]], device="cuda")
+                                   grow_t["kernel_ms"], float(checked), float(first_id), float(device)],
+                                  device="cuda" if args.backend == "nccl" else None)
 
     if rank == 0:
         agg = sharding.aggregate(allst)
@@ -368,18 +434,26 @@ def main():
                        # one workgroup (= one problem) per CU at a time: P problems run in ceil(P / 256) rounds
                        "workgroup_rounds": rounds, "last_round_fill": (P - (rounds - 1) * CUS) / CUS,
                        # what `dtype` means here: every value that enters a result (distances, steer, motion check, tree,
-                       # checksum) is computed in f64 in the reference's evaluation order; the resident_f32 / stream kernels
+                       # checksum) is computed in f64 in the reference's evaluation order; the lanes / stream kernels
                        # additionally SCREEN nearest-neighbour candidates in packed binary32 with a proven error bound and
                        # fall back to the f64 scan when the screen cannot decide -- bit-identical results
-                       "arithmetic": ("f64 results; packed-f32 candidate screen + f64 decision" if kname in ("resident_f32", "stream", "lanes")
+                       "arithmetic": ("f64 results; packed-f32 candidate screen + f64 decision" if kname in ("stream", "lanes")
                                       else "f64 throughout")},
             "roofline": roofline,
             "grow": {"iterations": float(allst[:, 4].sum()), "wall_s": float(allst[:, 5].max()),
                      "iterations_per_s": float(allst[:, 4].sum() / allst[:, 5].max()),
                      "kernel_ms_rank0": float(allst[0, 6]), "kernel": grow_kname},
             "per_rank": {"iterations_per_s_min": min(per_rank_its), "iterations_per_s_max": max(per_rank_its),
-                         "step_time_skew": float(allst[:, 0].max() / allst[:, 0].min())},
+                         "step_time_skew": float(allst[:, 0].max() / allst[:, 0].min()),
+                         "iterations_per_s": per_rank_its, "first_problem_id": [int(v) for v in allst[:, 8]],
+                         "device": [int(v) for v in allst[:, 9]], "kernel_ms_per_step": (allst[:, 2] / args.steps).tolist(),
+                         # N > 1: problems of its own shard each rank compared with the oracle (grow phase + frozen iterations)
+                         "problems_checked_against_oracle": [int(v) for v in allst[:, 7]]},
         }
+        if world > 1:
+            out["config"]["backend"] = args.backend + (" (RCCL)" if args.backend == "nccl" else " (CPU collective: a rehearsal)")
+            if len(set(out["per_rank"]["device"])) < world:
+                out["config"]["note"] = "ranks share a GPU (--device-map %s): a functional run of the N > 1 branch, not a scaling point" % args.device_map
         if copy_gbs is not None:
             out["hbm_copy_peak_GBps"] = copy_gbs
         if secondary_stream is not None:
@@ -392,16 +466,8 @@ def main():
         if secondary_star is not None:
             out["secondary_rrt_star"] = secondary_star
         if not args.no_cpu_baseline and world == 1:  # the contract: rank 0, N = 1 only
-            threads = min(os.cpu_count() or 1, 16, P)
-            frozen = args.iters * (args.steps + args.warmup)
-            if frozen <= 400000:
-                point = (frozen, c2)       # the whole frozen run, as timed
-            elif snap is not None:
-                point = snap               # a long run: compare at the last affordable warm-up boundary
-            else:
-                raise SystemExit("bench.py: %d frozen iterations per problem are too many for the CPU check and there is no "
-                                 "warm-up boundary to compare at; use --warmup >= 1 or --no-cpu-baseline" % frozen)
-            out["cpu_baseline"] = cpu_baseline_and_check(sc, seed, first_id, threads, point[0], c, point[1])
+            point = check_point()
+            out["cpu_baseline"] = cpu_baseline_and_check(sc, seed, first_id, P, point[0], c, point[1])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -23,7 +23,9 @@
 extern "C" {
 #endif
 
-#define OXHIP_ABI_VERSION 1
+/* 2: get_stamps takes a capacity (ABI 1 wrote 32, later 64 words unasked); kernel kinds 3 / 4 retired; the per-iteration checksum is
+ *    the polynomial H <- H P + g (ABI 1 as first shipped chained FNV-1a); oxhip_rrt_config gained goal_sampler / debug_flags */
+#define OXHIP_ABI_VERSION 2
 #define OXHIP_MAX_DIM 8
 
 /* Status codes.  0-5 mirror `PlanningError` (oxmpl/src/base/error.rs:97-108) in
@@ -74,17 +76,43 @@ typedef enum oxhip_space_kind {
                                      planner must be OXHIP_PLANNER_RRT_CONNECT; validity = oxhip_rrt_batch_set_segments */
 } oxhip_space_kind;
 
+/* GoalSampleableRegion::sample_goal of the ball goal (goal.rs:35-41; the trait leaves the distribution to the implementor).
+ * CENTRE: the ball's centre, no RNG word consumed -- README.md:160-162, oxmpl-js/examples/simple_2d_planning.js:30-33.
+ * UNIFORM_DISC: the sampler of the reference's own test fixtures, oxmpl/tests/rrt_rvss_tests.rs:55-66 (dim must be 2):
+ *   angle  = rng.random_range(0.0..2.0 * PI)      -- one u64 (52-bit transform)
+ *   radius = self.radius * rng.random::<f64>().sqrt()   -- one u64 (53 bits x 2^-53)
+ *   (x, y) = (cx + radius * angle.cos(), cy + radius * angle.sin())
+ * cos / sin are evaluated by the portable routine ox_sincos (oxmpl_amd/csrc/ox_sincos.hpp: Cody-Waite reduction + fdlibm
+ * kernels in unfused binary64; the test suite's CPU checker restates it operation for operation).  It differs from glibc's
+ * sin / cos by at most one ulp on [0, 2 PI) (the CPU test suite measures how often), so against a rustc-built oxmpl
+ * this mode is within north_star's 1e-6 relative bound rather than bit-exact. */
+typedef enum oxhip_goal_sampler {
+    OXHIP_GOAL_SAMPLE_CENTRE = 0,
+    OXHIP_GOAL_SAMPLE_UNIFORM_DISC = 1
+} oxhip_goal_sampler;
+
+/* oxhip_rrt_config.debug_flags (tests only; every switch leaves every result bit-identical) */
+typedef enum oxhip_debug_flag {
+    OXHIP_DEBUG_PAIR_TO_WHOLE_TREE = 1,   /* rrt_lanes.hip: two-lane near-ties take the whole-tree path like three-way ones */
+    OXHIP_DEBUG_AUDIT = 2,                /* rrt_lanes.hip, stamped build: count accepted motions whose end state is invalid (stamps[50]) */
+    OXHIP_DEBUG_ALL_WHOLE_TREE = 4,       /* rrt_lanes.hip: no screen verdict is trusted -- every query that is not answered from the memoized
+                                             whole-tree answer takes the whole-tree path (with goal_bias > 0 the memo is then hit constantly) */
+    OXHIP_DEBUG_ONE_LANE_ROUNDS = 8,      /* rrt_lanes.hip: a round commits one lane; the others are re-resolved against the grown tree */
+    OXHIP_DEBUG_SHORT_MEMO = 16,          /* rrt_lanes.hip: the memoized answer expires after 8 inserts instead of (ring - 64) */
+    OXHIP_DEBUG_STAR_TWO_PASS = 32,       /* rrt_star_wire.hip: neighbour lists by a second search instead of the counting pass's chunks */
+    OXHIP_DEBUG_STAR_ONE_SEGMENT = 64     /* rrt_star_wire.hip: one edge-check segment, no overlap with the wiring stream */
+} oxhip_debug_flag;
+
 typedef enum oxhip_kernel_kind {
-    OXHIP_KERNEL_AUTO = 0,      /* OXHIP_KERNEL_LANES when the tree fits its register rows (R^2 .. R^6), else the older resident
-                                   kernels (R^2 / R^3), else streaming */
-    OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration */
-    OXHIP_KERNEL_RESIDENT = 2,  /* tree held in the workgroup's vector registers, every node scanned */
-    OXHIP_KERNEL_PRUNED = 3,    /* experiment, only in builds made with WITH_PRUNED=1 (else OXHIP_ERR_BAD_ARG): resident + box-pruned scan */
-    OXHIP_KERNEL_RESIDENT_F32 = 4, /* resident, the scanners screen in packed binary32 and the resolver decides in binary64
-                                     from the binary64 nodes: same results bit for bit (rrt_resident32.hip) */
-    OXHIP_KERNEL_LANES = 5        /* resident + binary32 screen with a lane-per-query resolver: up to 64 iterations are
-                                     resolved side by side and committed as the longest prefix that keeps the reference's
-                                     sequential semantics (rrt_lanes.hip); same results bit for bit */
+    OXHIP_KERNEL_AUTO = 0,      /* OXHIP_KERNEL_LANES when the tree fits its register rows (R^2 .. R^6), else streaming */
+    OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration: any dimension <= 8, any tree size */
+    OXHIP_KERNEL_RESIDENT = 2,  /* tree held in the workgroup's vector registers as binary64, every node scanned in binary64
+                                   (R^2 / R^3, <= 10,240 nodes): no binary32 anywhere -- the cross-check of the screened kernels */
+    OXHIP_KERNEL_RETIRED_3 = 3, /* (ABI 1: box-pruned resident scan, an experiment) -- OXHIP_ERR_BAD_ARG since ABI 2 */
+    OXHIP_KERNEL_RETIRED_4 = 4, /* (ABI 1: binary32 screen + lane-group resolver, round 1's default) -- OXHIP_ERR_BAD_ARG since ABI 2 */
+    OXHIP_KERNEL_LANES = 5      /* resident + binary32 screen with a lane-per-query resolver: up to 64 iterations are
+                                   resolved side by side and committed as the longest prefix that keeps the reference's
+                                   sequential semantics (rrt_lanes.hip); same results bit for bit */
 } oxhip_kernel_kind;
 
 /* RRT::new(max_distance, goal_bias) (rrt.rs:75-83) + RealVectorStateSpace::new(dim, bounds)
@@ -108,7 +136,12 @@ typedef struct oxhip_rrt_config {
     double   search_radius;             /* RRTStar::search_radius (rrt_star.rs:45): neighbours are the nodes with
                                            distance < search_radius (strict); ignored by the other planners */
     uint32_t space;                     /* oxhip_space_kind */
-    uint32_t reserved;                  /* 0 */
+    uint32_t goal_sampler;              /* oxhip_goal_sampler: what GoalSampleableRegion::sample_goal (goal.rs:35-41) draws */
+    uint32_t debug_flags;               /* oxhip_debug_flag bits: test-only switches that force rarely taken code paths; results are
+                                           identical by construction.  0 in production (the library reads no environment variable) */
+    uint32_t star_pool_share;           /* RRT*, decoupled design: neighbour-list pool entries per problem (16 B each, + 4.5 B of chunk
+                                           store); 0 = default: 64 x tree capacity, bounded so that the whole batch stays below 24 GB.
+                                           The size bounds memory, never results: lists that do not fit are wired in further rounds */
 } oxhip_rrt_config;
 
 typedef struct oxhip_rrt_batch oxhip_rrt_batch;
@@ -143,7 +176,7 @@ int32_t oxhip_rrt_batch_set_segments(oxhip_rrt_batch* b, const double* segments 
 /* Planner::setup (rrt.rs:140-156) for every problem: clears the tree, pushes start_states[0]
  * (validity of the start is NOT checked, as in the reference), resets counters and the RNG
  * stream.  Goal = ball: is_satisfied(s) = distance(s, centre) <= radius
- * (rrt_rvss_tests.rs:45-49); sample_goal() = centre and draws nothing (README.md:160-162). */
+ * (rrt_rvss_tests.rs:45-49); sample_goal() as oxhip_rrt_config.goal_sampler says. */
 int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts /*[P][dim]*/,
                               const double* goal_centres /*[P][dim]*/, const double* goal_radii /*[P]*/);
 
@@ -199,12 +232,18 @@ int32_t oxhip_rrt_batch_get_costs(oxhip_rrt_batch* b, uint32_t problem, double* 
 int32_t oxhip_rrt_batch_last_timing(oxhip_rrt_batch* b, double* kernel_ms, uint32_t* launches,
                                     uint32_t* kernel_kind);
 
-/* Diagnostics: in-kernel cycle stamps of workgroup 0 of the resident kernel (a separately
- * instantiated diagnostic build; never time that build).  out[32]: cycles spent by thread 0 in
- * {0 scan+publish, 1 barrier-1 wait, 2 resolve, 3 -, 4 motion check / next sample, 5 barrier-3 wait,
- *  6 verdict+insert, 7 iterations}; out[16+w]: wave w's summed (barrier-1 arrival - barrier-3 release). */
+/* Diagnostics: in-kernel counters and cycle stamps of the resident kernels (a separately instantiated
+ * diagnostic build; never time that build).  Up to OXHIP_STAMP_WORDS words; get_stamps writes
+ * min(cap_words, OXHIP_STAMP_WORDS) of them.  rrt_lanes.hip (workgroup 0 unless noted): [1] resolver wait,
+ * [2] work, [3] whole-tree-path cycles; [4] whole-tree-path events, [5] rounds, [6] lanes offered,
+ * [7] iterations, [11] memoized answers used, [12] conflict cuts, [15] literal-loop ties,
+ * [16+w] / [24+w] scanner wave w wait / work cycles, [32..39] resolver phases, [40..43] fold / conflict
+ * trips and exact evaluations, [44..48] batch-wide maxima and sums, [50..53] audit (OXHIP_DEBUG_AUDIT),
+ * [54] batch-wide whole-tree events, [55] memo hits, [56] conflict cuts, [57] ring wraps (rounds in which the
+ * committed-node ring passed a multiple of its size), [58] two-lane passes. */
+#define OXHIP_STAMP_WORDS 64
 int32_t oxhip_rrt_batch_enable_stamps(oxhip_rrt_batch* b, uint32_t enable);
-int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out /*[64]*/);
+int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out, uint32_t cap_words);
 
 /* ---- stand-alone batched primitives (same device functions as the planner kernels) ---- */
 

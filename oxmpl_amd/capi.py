@@ -18,7 +18,13 @@ OK, ERR_TIMEOUT, ERR_NO_SOLUTION_FOUND, ERR_PLANNER_UNINITIALISED = 0, 1, 2, 3
 ERR_INVALID_START_STATE, ERR_UNSAMPLED_STATE_SPACE = 4, 5
 ERR_BAD_ARG, ERR_UNBOUNDED, ERR_ZERO_VOLUME, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE = 16, 17, 18, 19, 32, 33
 STOP_NONE, STOP_GOAL, STOP_ITERATIONS, STOP_NODES, STOP_TIMEOUT = -1, 0, 1, 2, 3
-KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT, KERNEL_PRUNED, KERNEL_RESIDENT_F32, KERNEL_LANES = 0, 1, 2, 3, 4, 5
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT, KERNEL_LANES = 0, 1, 2, 5   # (3 and 4 were retired with ABI version 2)
+GOAL_SAMPLE_CENTRE, GOAL_SAMPLE_UNIFORM_DISC = 0, 1
+# oxhip_debug_flag: test-only switches that force rarely taken code paths (results identical by construction)
+DEBUG_PAIR_TO_WHOLE_TREE, DEBUG_AUDIT, DEBUG_ALL_WHOLE_TREE, DEBUG_ONE_LANE_ROUNDS, DEBUG_SHORT_MEMO = 1, 2, 4, 8, 16
+DEBUG_STAR_TWO_PASS, DEBUG_STAR_ONE_SEGMENT = 32, 64
+ABI_VERSION = 2
+STAMP_WORDS = 64
 PLANNER_RRT, PLANNER_RRT_CONNECT, PLANNER_RRT_STAR = 0, 1, 2
 SPACE_REAL_VECTOR, SPACE_SE2 = 0, 1
 
@@ -46,7 +52,7 @@ class Config(C.Structure):
         ("n_problems", C.c_uint32), ("max_nodes", C.c_uint32), ("stop_at_goal", C.c_uint32),
         ("kernel", C.c_uint32), ("seed", C.c_uint64), ("first_problem_id", C.c_uint64),
         ("device", C.c_int32), ("planner", C.c_uint32), ("search_radius", C.c_double),
-        ("space", C.c_uint32), ("reserved", C.c_uint32),
+        ("space", C.c_uint32), ("goal_sampler", C.c_uint32), ("debug_flags", C.c_uint32), ("star_pool_share", C.c_uint32),
     ]
 
 
@@ -117,7 +123,7 @@ def lib():
         L.oxhip_rrt_batch_get_costs.argtypes = [C.c_void_p, C.c_uint32, _dp, C.c_uint32, _u32p]
         L.oxhip_rrt_batch_last_timing.argtypes = [C.c_void_p, _dp, _u32p, _u32p]
         L.oxhip_rrt_batch_enable_stamps.argtypes = [C.c_void_p, C.c_uint32]
-        L.oxhip_rrt_batch_get_stamps.argtypes = [C.c_void_p, _u64p]
+        L.oxhip_rrt_batch_get_stamps.argtypes = [C.c_void_p, _u64p, C.c_uint32]
         L.oxhip_nn_argmin_batch.argtypes = [C.c_int32, C.c_uint32, _dp, _u32p, C.c_uint32, _dp, _u32p, _dp]
         L.oxhip_distance_batch.argtypes = [C.c_int32, C.c_uint32, _dp, _dp, C.c_uint32, _dp]
         L.oxhip_interpolate_batch.argtypes = [C.c_int32, C.c_uint32, _dp, _dp, _dp, C.c_uint32, _dp]
@@ -179,7 +185,8 @@ class RRTBatch:
 
     def __init__(self, dim, bounds, max_distance, goal_bias, n_problems, max_nodes=10000,
                  lvs_fraction=0.05, stop_at_goal=True, seed=0, first_problem_id=0, device=0,
-                 kernel=KERNEL_AUTO, planner=PLANNER_RRT, search_radius=0.0, space=SPACE_REAL_VECTOR):
+                 kernel=KERNEL_AUTO, planner=PLANNER_RRT, search_radius=0.0, space=SPACE_REAL_VECTOR,
+                 goal_sampler=GOAL_SAMPLE_CENTRE, debug_flags=0, star_pool_share=0):
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
         cfg.dim = dim
@@ -195,6 +202,7 @@ class RRTBatch:
         cfg.planner = planner
         cfg.search_radius = search_radius
         cfg.space = space
+        cfg.goal_sampler, cfg.debug_flags, cfg.star_pool_share = goal_sampler, debug_flags, star_pool_share
         self.planner = planner
         self.dim, self.n_problems, self.max_nodes = dim, n_problems, max_nodes
         self._h = C.c_void_p()
@@ -303,8 +311,8 @@ class RRTBatch:
         _check(lib().oxhip_rrt_batch_enable_stamps(self._h, int(bool(enable))))
 
     def stamps(self):
-        out = np.zeros(64, dtype=np.uint64)
-        _check(lib().oxhip_rrt_batch_get_stamps(self._h, _p(out, _u64p)))
+        out = np.zeros(STAMP_WORDS, dtype=np.uint64)
+        _check(lib().oxhip_rrt_batch_get_stamps(self._h, _p(out, _u64p), STAMP_WORDS))
         return out
 
     def is_valid(self, states):

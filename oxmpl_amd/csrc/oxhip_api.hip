@@ -7,7 +7,6 @@
 // entry point that computes returns OXHIP_ERR_NO_DEVICE.
 #include "../../include/oxmpl_hip.h"
 
-#include <cstdlib>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -23,19 +22,12 @@
 
 using namespace oxhip;
 
-#ifndef OXHIP_WITH_PRUNED   // the pruned-scan experiment is left out of the product build (Makefile: WITH_PRUNED=1)
-namespace oxhip {
-bool pruned_supported(uint32_t, uint32_t) { return false; }
-void launch_rrt_pruned(const DevParams&, hipStream_t) {}
-}
-#endif
-
 struct oxhip_rrt_batch {
     oxhip_rrt_config cfg{};
     DevParams dp{};
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    DevBuf<double> tree, goal_c, goal_thr, sph_c, sph_thr, sph_filt, box_lo, box_hi;
+    DevBuf<double> tree, goal_c, goal_thr, goal_r, sph_c, sph_thr, sph_filt, box_lo, box_hi;
     std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
     bool filt_dirty = true;
     DevBuf<double> tree_b;   // RRTConnect goal trees
@@ -112,6 +104,8 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (!(cfg->max_distance > 0.0) || !std::isfinite(cfg->max_distance))
         return fail(OXHIP_ERR_BAD_ARG, "max_distance must be finite and > 0");
     if (cfg->kernel > OXHIP_KERNEL_LANES) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
+    if (cfg->kernel == OXHIP_KERNEL_RETIRED_3 || cfg->kernel == OXHIP_KERNEL_RETIRED_4)
+        return fail(OXHIP_ERR_BAD_ARG, "kernel kinds 3 (box-pruned scan) and 4 (lane-group resolver) were retired in ABI version 2");
     if (cfg->planner > OXHIP_PLANNER_RRT_STAR) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
     if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
         return fail(OXHIP_ERR_BAD_ARG, "RRTConnect runs on the stream kernel only");
@@ -122,6 +116,9 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_BAD_ARG, "RRT* runs on the stream kernel or on the lane-per-query kernel + wiring kernels");
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR && std::isnan(cfg->search_radius))
         return fail(OXHIP_ERR_BAD_ARG, "search_radius is NaN");
+    if (cfg->goal_sampler > OXHIP_GOAL_SAMPLE_UNIFORM_DISC) return fail(OXHIP_ERR_BAD_ARG, "unknown goal sampler");
+    if (cfg->goal_sampler == OXHIP_GOAL_SAMPLE_UNIFORM_DISC && (cfg->dim != 2 || cfg->space != OXHIP_SPACE_REAL_VECTOR))
+        return fail(OXHIP_ERR_BAD_ARG, "the disc sampler (rrt_rvss_tests.rs:55-66) is defined for RealVectorStateSpace(2)");
     double fraction = cfg->lvs_fraction, res = 0.0;
     double th_lo = 0.0, th_hi = 0.0;
     if (cfg->space > OXHIP_SPACE_SE2) return fail(OXHIP_ERR_BAD_ARG, "unknown space kind");
@@ -169,11 +166,8 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.res = res;
     dp.p_int = bernoulli_p_int(cfg->goal_bias);
     dp.seed = cfg->seed;
-    {   // diagnosis / regression tests only: OXHIP_DEBUG_FLAGS bit 0 = the lane-per-query kernel sends two-lane cases to its
-        // whole-tree path as well (that path is otherwise reached by three-way near-ties only)
-        const char* e = std::getenv("OXHIP_DEBUG_FLAGS");
-        dp.dbg_flags = e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u;
-    }
+    dp.dbg_flags = cfg->debug_flags;   // oxhip_debug_flag bits: test-only, results identical (the library reads no environment variable)
+    dp.goal_sampler = cfg->goal_sampler;
     dp.first_problem_id = cfg->first_problem_id;
     dp.stop_at_goal = cfg->stop_at_goal ? 1 : 0;
     dp.t_steer = sqrt_le_threshold(cfg->max_distance);
@@ -200,32 +194,44 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         }
         chk(b->cost.alloc((size_t)P * cap));
         chk(b->wire_chk.alloc(P));
-        if (b->star_wired) {
+        if (b->star_wired && e == hipSuccess) {
             // neighbour lists: a pool segment per problem; a round wires the longest prefix of a problem's pending nodes whose
-            // lists fit (mean list length at radius 1 in configs[1]'s world: ~40), so the size bounds memory, not the result
+            // lists fit (mean list length at radius 1 in configs[1]'s world: ~40), so the size bounds memory, not the result.
+            // Footprint per problem: share x 16 B of pool + (share / 32 + cap) x 144 B of chunk store + 4 x cap x 4..8 B; the
+            // default share is 64 x cap, cut so that pool + chunks of the whole batch stay below 24 GB.
             uint64_t share = 64ull * cap;
-            const uint64_t budget_entries = (24ull << 30) / sizeof(StarEntry) / P;
+            const uint64_t budget_entries = (24ull << 30) / (sizeof(StarEntry) + sizeof(StarChunk) / 32) / P;
             if (share > budget_entries) share = budget_entries;
-            if (const char* e = std::getenv("OXHIP_STAR_POOL_SHARE")) {   // tests: a small segment forces many wiring rounds
-                const uint64_t v = std::strtoull(e, nullptr, 0);
-                if (v != 0 && v < share) share = v;
-            }
+            if (cfg->star_pool_share != 0 && cfg->star_pool_share < share) share = cfg->star_pool_share;
             if (share < cap) share = cap;   // a single list is at most cap entries long: every round wires at least one node
             dp.pool_share = (uint32_t)share;
-            chk(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
-            for (auto& ev : b->ev_seg) chk(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            chk(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
-            chk(b->pool.alloc((size_t)P * share + 64));   // (+ padding: masked lanes of the wiring kernel read one entry past an empty list)
+            hipError_t ew = hipSuccess;
+            auto chkw = [&](hipError_t r) { if (ew == hipSuccess) ew = r; };
+            chkw(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+            for (auto& ev : b->ev_seg) chkw(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            chkw(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+            chkw(b->pool.alloc((size_t)P * share + 64));   // (+ padding: masked lanes of the wiring kernel read one entry past an empty list)
             dp.chunk_share = (uint32_t)(share / 32 + cap);   // enough for any set of lists that fits the pool segment (one partial chunk per node)
-            chk(b->chunks.alloc((size_t)P * dp.chunk_share));
-            chk(b->chunk_cursor.alloc(P));
-            chk(b->wired.alloc(P));
-            chk(b->nbr_take.alloc(P));
-            chk(b->nbr_total.alloc(P));
-            chk(b->nbr_cnt.alloc((size_t)P * cap));
-            chk(b->nbr_off.alloc((size_t)P * cap));
-            chk(b->d_near.alloc((size_t)P * cap));
-        } else {
+            chkw(b->chunks.alloc((size_t)P * dp.chunk_share));
+            chkw(b->chunk_cursor.alloc(P));
+            chkw(b->wired.alloc(P));
+            chkw(b->nbr_take.alloc(P));
+            chkw(b->nbr_total.alloc(P));
+            chkw(b->nbr_cnt.alloc((size_t)P * cap));
+            chkw(b->nbr_off.alloc((size_t)P * cap));
+            chkw(b->d_near.alloc((size_t)P * cap));
+            if (ew != hipSuccess && cfg->kernel == OXHIP_KERNEL_AUTO) {
+                // KERNEL_AUTO promised "whatever runs": the one-kernel design (rrt_star.hip) needs 1/60 of this memory
+                (void)hipGetLastError();
+                b->pool.release(); b->chunks.release(); b->chunk_cursor.release(); b->wired.release(); b->nbr_take.release();
+                b->nbr_total.release(); b->nbr_cnt.release(); b->nbr_off.release(); b->d_near.release();
+                dp.pool_share = dp.chunk_share = 0;
+                b->star_wired = false;
+            } else {
+                chk(ew);
+            }
+        }
+        if (!b->star_wired) {
             chk(b->nb_idx.alloc((size_t)P * cap));
             chk(b->nb_dist.alloc((size_t)P * cap));
         }
@@ -233,6 +239,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     chk(b->state.alloc(P));
     chk(b->goal_c.alloc((size_t)P * dim));
     chk(b->goal_thr.alloc(P));
+    chk(b->goal_r.alloc(P));
     if (e != hipSuccess) {
         std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e);
         oxhip_rrt_batch_destroy(b);
@@ -244,25 +251,15 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.wire_chk = b->wire_chk.p; dp.wired = b->wired.p; dp.nbr_cnt = b->nbr_cnt.p; dp.nbr_off = b->nbr_off.p;
     dp.nbr_take = b->nbr_take.p; dp.nbr_total = b->nbr_total.p; dp.d_near = b->d_near.p; dp.pool = b->pool.p;
     dp.chunks = b->chunks.p; dp.chunk_cursor = b->chunk_cursor.p;
-    dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p;
+    dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p; dp.goal_r = b->goal_r.p;
 
     uint32_t kind = cfg->kernel;
     if (cfg->planner != OXHIP_PLANNER_RRT) kind = b->star_wired ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO)
-        kind = lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES
-             : resident32_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT_F32
-             : resident_supported(dim, cap) ? OXHIP_KERNEL_RESIDENT : OXHIP_KERNEL_STREAM;
-    if (kind == OXHIP_KERNEL_PRUNED && !pruned_supported(dim, cap)) {
-        oxhip_rrt_batch_destroy(b);
-        return fail(OXHIP_ERR_BAD_ARG, "resident (pruned) kernel: not in this build (make WITH_PRUNED=1) or no instantiation for this (dim, max_nodes)");
-    }
+        kind = lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_LANES && !lanes_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
         return fail(OXHIP_ERR_BAD_ARG, "resident (lane-per-query) kernel does not support this (dim, max_nodes)");
-    }
-    if (kind == OXHIP_KERNEL_RESIDENT_F32 && !resident32_supported(dim, cap)) {
-        oxhip_rrt_batch_destroy(b);
-        return fail(OXHIP_ERR_BAD_ARG, "resident (f32 screen) kernel does not support this (dim, max_nodes)");
     }
     if (kind == OXHIP_KERNEL_RESIDENT && !resident_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
@@ -367,6 +364,9 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
     for (size_t i = 0; i < (size_t)P * dim; ++i)
         if (!(std::fabs(starts[i]) <= kMaxMagnitude) || !(std::fabs(goal_centres[i]) <= kMaxMagnitude))
             return fail(OXHIP_ERR_BAD_ARG, "start / goal centre not finite or beyond 1e150");
+    if (b->cfg.goal_sampler == OXHIP_GOAL_SAMPLE_UNIFORM_DISC)
+        for (uint32_t p = 0; p < P; ++p)
+            if (!(goal_radii[p] >= 0.0 && goal_radii[p] <= kMaxMagnitude)) return fail(OXHIP_ERR_BAD_ARG, "disc sampler: goal radius must be finite and >= 0");
     b->starts.assign(starts, starts + (size_t)P * dim);
     b->filt_dirty = true;
     std::vector<double> thr(P);
@@ -385,6 +385,7 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
     std::vector<int32_t> root(1, -1);
     HIP_TRY(hipMemcpyAsync(b->goal_c.p, goal_centres, (size_t)P * dim * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->goal_thr.p, thr.data(), P * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->goal_r.p, goal_radii, P * sizeof(double), hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemcpyAsync(b->state.p, states.data(), P * sizeof(ProblemState), hipMemcpyHostToDevice, b->stream));
     // tree.clear(); tree.push(Node{start_states[0], None})   rrt.rs:147-155
     // node 0 of coordinate k of problem p lives at tree[(p*dim + k)*cap]: strided 2-D copy
@@ -548,7 +549,7 @@ static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
         // built from its chunks; otherwise (a pool segment or the chunk store ran out) the round searches a second time
         HIP_TRY(hipMemcpyAsync(chunks_used.data(), b->chunk_cursor.p, (size_t)P * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
-        bool one_pass = std::getenv("OXHIP_STAR_TWO_PASS") == nullptr;
+        bool one_pass = (b->dp.dbg_flags & OXHIP_DEBUG_STAR_TWO_PASS) == 0;
         uint32_t max_chunks = 0;
         for (uint32_t p = 0; p < P; ++p) {
             const uint32_t pend = states[p].n_nodes > wired[p] ? states[p].n_nodes - wired[p] : 0u;
@@ -560,7 +561,7 @@ static int32_t wire_new_nodes(oxhip_rrt_batch* b) {
         // The pairs are checked segment by segment (of the entries) and a segment's nodes -- those whose lists end inside it --
         // are wired on a second stream meanwhile: the wiring kernel is one latency-bound wave per problem and shares the
         // chip with the next segment's throughput-bound edge kernel at almost no cost to either
-        const uint32_t segs = (max_total >= 64u * 1024u && std::getenv("OXHIP_STAR_ONE_SEGMENT") == nullptr) ? 8u : 1u;
+        const uint32_t segs = (max_total >= 64u * 1024u && (b->dp.dbg_flags & OXHIP_DEBUG_STAR_ONE_SEGMENT) == 0) ? 8u : 1u;
         for (uint32_t sgi = 0; sgi < segs; ++sgi) {
             b->dp.seg_index = sgi;
             b->dp.seg_count = segs;
@@ -603,7 +604,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         b->dp.budget = step;
         b->dp.freeze = freeze ? 1 : 0;
         // KERNEL_AUTO = the lane-per-query kernel wherever it exists (R^2 .. R^6, trees that fit its register rows), for frozen
-        // and growing launches alike (grow: 297 M it/s against 288 M for rrt_resident32.hip's lane-group resolver)
+        // and growing launches alike; the stream kernel for everything else
         uint32_t kind = b->kernel_kind;
         b->last_kind = kind;
         HIP_TRY(hipEventRecord(b->ev0, b->stream));
@@ -616,9 +617,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
             if ((st = wire_new_nodes(b)) != OXHIP_OK) return st;
         }
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) launch_rrt_star(b->dp, b->stream);
-        else if (kind == OXHIP_KERNEL_PRUNED) launch_rrt_pruned(b->dp, b->stream);
         else if (kind == OXHIP_KERNEL_LANES) launch_rrt_lanes(b->dp, b->stream);
-        else if (kind == OXHIP_KERNEL_RESIDENT_F32) launch_rrt_resident32(b->dp, b->stream);
         else if (kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
         else launch_rrt_stream(b->dp, b->stream);
         HIP_TRY(hipGetLastError());
@@ -835,8 +834,8 @@ int32_t oxhip_rrt_batch_enable_stamps(oxhip_rrt_batch* b, uint32_t enable) {
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
     if (enable) {
-        HIP_TRY(b->dbg.alloc(64));
-        HIP_TRY(hipMemsetAsync(b->dbg.p, 0, 64 * sizeof(uint64_t), b->stream));
+        HIP_TRY(b->dbg.alloc(OXHIP_STAMP_WORDS));
+        HIP_TRY(hipMemsetAsync(b->dbg.p, 0, OXHIP_STAMP_WORDS * sizeof(uint64_t), b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));
         b->dp.dbg = b->dbg.p;
     } else {
@@ -845,12 +844,13 @@ int32_t oxhip_rrt_batch_enable_stamps(oxhip_rrt_batch* b, uint32_t enable) {
     return OXHIP_OK;
 }
 
-int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out) {
+int32_t oxhip_rrt_batch_get_stamps(oxhip_rrt_batch* b, uint64_t* out, uint32_t cap_words) {
     if (!b || !out) return fail(OXHIP_ERR_BAD_ARG, "null argument");
     if (!b->dp.dbg) return fail(OXHIP_ERR_BAD_ARG, "stamps are not enabled");
     int32_t st = select_device(b->cfg.device);
     if (st != OXHIP_OK) return st;
-    HIP_TRY(hipMemcpyAsync(out, b->dbg.p, 64 * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
+    const uint32_t n = cap_words < OXHIP_STAMP_WORDS ? cap_words : OXHIP_STAMP_WORDS;
+    if (n) HIP_TRY(hipMemcpyAsync(out, b->dbg.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     return OXHIP_OK;
 }

@@ -82,7 +82,8 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { release(); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
     hipError_t alloc(size_t count) {
         if (p) { (void)hipFree(p); p = nullptr; }
         n = count;

@@ -51,17 +51,9 @@ void launch_star_wire(const DevParams& p, hipStream_t stream);                  
 bool resident_supported(uint32_t dim, uint32_t cap);
 void launch_rrt_resident(const DevParams& p, hipStream_t stream);
 
-// rrt_resident32.hip: the resident pipeline with a binary32 screen in the scanner waves (exact results)
-bool resident32_supported(uint32_t dim, uint32_t cap);
-void launch_rrt_resident32(const DevParams& p, hipStream_t stream);
-
 // rrt_lanes.hip: the resident pipeline with a lane-per-query resolver (64 iterations resolved side by side)
 bool lanes_supported(uint32_t dim, uint32_t cap);
 void launch_rrt_lanes(const DevParams& p, hipStream_t stream);
-
-// rrt_pruned.hip: the resident pipeline + launch-time spatial sort and box-pruned scans
-bool pruned_supported(uint32_t dim, uint32_t cap);
-void launch_rrt_pruned(const DevParams& p, hipStream_t stream);
 
 // prm_kernels.hip: PRM roadmap construction / query (prm.rs)
 struct PrmState {            // persists in HBM between launches

@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/oxmpl_hip.h"   // the enums the kernels share with the boundary (debug flags, goal sampler)
+
 namespace oxhip {
 
 constexpr int kMaxDim = 8;
@@ -37,7 +39,8 @@ struct ProblemState {
     uint32_t pad;
 };
 
-// one neighbour of one node (rrt_star_wire.hip): written as (j, 0, d2) by the pair search, completed by the edge kernel
+// one neighbour of one node (rrt_star_wire.hip): written as (j, owner node i, d2) by the pair search -- the edge kernel reads the
+// owner from `flags` -- and completed by the edge kernel (validity bits, distance)
 struct StarEntry {
     uint32_t j;        // the neighbour's index (< the node's own)
     uint32_t flags;    // bit 0: check_motion(neighbour, node) holds; bit 1: check_motion(node, neighbour) holds
@@ -105,7 +108,9 @@ struct DevParams {
     // binary32 screen of the streaming kernels (rrt_stream.hip, rrt_star.hip): fl32 shadow of the tree
     float* tree32;          // [P][dim][cap] fl32(tree), same layout; maintained by the kernels that insert
     uint32_t* shadow_state; // [P][2]: nodes whose shadow is valid; bits of the largest |fl32(coordinate)| among them
-    uint32_t dbg_flags;     // OXHIP_DEBUG_FLAGS (environment, read at batch creation): bit 0 = rrt_lanes.hip without its two-lane pass; bit 1 = the diagnostic instantiation audits every accepted end state against the spheres (64 binary64 distances per query: off when timing with stamps)
+    uint32_t dbg_flags;     // oxhip_rrt_config.debug_flags (oxhip_debug_flag bits): test-only switches, results identical
+    uint32_t goal_sampler;  // oxhip_goal_sampler
+    const double* goal_r;   // [P] goal radii as given (the disc sampler scales by them)
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -408,11 +413,19 @@ __device__ __forceinline__ bool motion_invalid_wg(const DevParams& p, int dim, c
     return bad;
 }
 
-// ---------------------------------------------------------------- binary32 screen (error model: rrt_resident32.hip)
-// A node whose binary32 squared distance (computed from fl32 inputs) is v lies at true distance
-//   sqrt(v)(1 - R) - A <= d <= sqrt(v)(1 + R) + A,  A = sqrt(D) 4.1 u M + 1e-18,  R = 2^-19 + (D + 2) u,  u = 2^-24,
-// M = largest coordinate magnitude in play.  The kernels use 2A and 2R: a screen winner is accepted only when the
-// runner-up's lower bound exceeds its upper bound; the result is then computed in binary64 from the binary64 node.
+// ---------------------------------------------------------------- binary32 screen of a squared distance
+// (stream kernel, RRT*, RRTConnect: the scan of rrt.rs:187-196 run over an fl32 shadow of the tree; it only names a candidate.)
+// Error model (u = 2^-24; M = largest coordinate magnitude among the bounds, the goal centre and the tree: every query is a
+// sample inside the bounds or the goal centre, every new node a convex combination of two of those):
+//   e_k = fl32(fl32(q_k) - fl32(c_k))             |e_k - (q_k - c_k)| <= u|q_k| + u|c_k| + u|e_k|  <= 4.1 u M
+//   s   = fma(e_2,e_2, fma(e_1,e_1, e_0*e_0))     s = |e|^2 (1 + eta) + zeta, |eta| <= D u, |zeta| <= D 2^-126
+// (+ a relative 2^-18 of slack kept from the round-1 kernel that stole the low 5 bits of s for a slot number), so a node whose
+// binary32 squared distance is v lies at true distance
+//   sqrt(v)(1 - R) - A <= d <= sqrt(v)(1 + R) + A,  A = sqrt(D) 4.1 u M + 1e-18,  R = 2^-19 + (D + 2) u.
+// The kernels use 2A and 2R: a screen winner is accepted only when the runner-up's lower bound exceeds its upper bound -- every
+// other screened node is then farther by at least ~1e-7 M, eleven orders of magnitude above the rounding of the binary64
+// post-sqrt compare of rrt.rs:192, so strict-'<' / lowest-index semantics cannot be involved; the result is then computed in
+// binary64 from the binary64 node.
 struct ScreenMargins {
     double a2, r_lo, r_hi;
     bool usable;   // M small enough for binary32 squares

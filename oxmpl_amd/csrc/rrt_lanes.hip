@@ -1,6 +1,6 @@
 // rrt_lanes.hip -- the register-resident RRT grow kernel: binary32 dot-product SCREEN + lane-per-query resolver.
 //
-// The tree of one planning problem lives in the vector registers of eight scanner waves, as in rrt_resident32.hip, but
+// The tree of one planning problem lives in the vector registers of eight scanner waves, as in rrt_resident.hip, but
 // both ends of the pipeline are rebuilt around what the chip actually issues (tools/valu_mix_bench.hip: every VALU
 // instruction of the old screen -- packed f32, and_or, med3, min -- costs one ~1.9 ns issue slot per wave64):
 //
@@ -50,8 +50,10 @@ constexpr int kLanesThreads = kScanThreads + 128;   // + the resolver wave + the
 #define OXHIP_LANES_QRING 128
 #endif
 constexpr int kQRing = OXHIP_LANES_QRING;           // queries in flight (power of two)
-constexpr int kNRing = 2 * kQRing;                  // committed nodes kept in LDS (power of two, >= kQRing + 64)
-static_assert((kQRing & (kQRing - 1)) == 0 && kNRing >= kQRing + 64, "ring sizes");
+constexpr int kNRing = 2 * kQRing;                  // committed nodes kept in LDS (power of two)
+// The resolver stages up to 64 would-be nodes in the slots n .. n + 63, i.e. over the nodes n - kNRing ..; a scanner may still
+// have to absorb nodes as old as n - (kQRing + one pass of 8 queries): the ring must hold both.
+static_assert((kQRing & (kQRing - 1)) == 0 && kNRing >= kQRing + 64 + 8, "ring sizes");
 #ifndef OXHIP_LANES_PASS3
 #define OXHIP_LANES_PASS3 8
 #endif
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
     uint32_t n = st.n_nodes;
     uint32_t jr = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
-    uint64_t n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, n_pair = 0, n_fold_trips = 0, n_fold_exact = 0, n_conf_trips = 0, n_conf_exact = 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = STAMP ? (uint64_t)clock64() : 0;
+    uint64_t n_wrap = 0, n_forced = 0, n_amb = 0, n_rounds = 0, n_lanes = 0, n_cut_conflict = 0, t_wait = 0, t_work = 0, t_exact = 0, n_tie = 0, n_memo = 0, n_pair = 0, n_fold_trips = 0, n_fold_exact = 0, n_conf_trips = 0, n_conf_exact = 0, t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_mark = STAMP ? (uint64_t)clock64() : 0;
     const uint64_t t_begin = t_mark, rt_begin = STAMP ? (uint64_t)__builtin_amdgcn_s_memrealtime() : 0;
 
     __syncthreads();  // pairs with the scanners' second barrier: mabs_bits is final
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         // with that very query -- the goal centre, drawn again and again: when the screen cannot decide it once it cannot the
         // next time either -- starts from that answer and only has to look at the nodes committed since (they are in the LDS
         // ring), instead of ending the round's prefix and scanning the whole tree every time.
-        bool from_memo = act && memo_n <= n && n - memo_n <= (uint32_t)(kNRing - 64);
+        bool from_memo = act && memo_n <= n && n - memo_n <= ((p.dbg_flags & OXHIP_DEBUG_SHORT_MEMO) ? 8u : (uint32_t)(kNRing - 64));
 #pragma unroll
         for (int k = 0; k < D; ++k) from_memo = from_memo && __double_as_longlong(q[k]) == __double_as_longlong(memo_q[k]);
         if (from_memo) {
@@ -790,7 +792,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         uint32_t wthread2 = 0xFFFFFFFFu;
         if (waves_out && (wth & 0x40000000u) != 0) wthread2 = (wth & 0x1C0u) | ((wth >> 16) & 63u);
         else if (!flag1 && !waves_out && (double)K3 > m225 && (wth2 & 0x80000000u) == 0) wthread2 = wth2 & 0x1FFu;
-        const bool pair = OXHIP_LANES_PAIR && (p.dbg_flags & 1u) == 0 && act && !from_memo && mg.usable && wthread2 != 0xFFFFFFFFu;
+        const bool pair = OXHIP_LANES_PAIR && (p.dbg_flags & (OXHIP_DEBUG_PAIR_TO_WHOLE_TREE | OXHIP_DEBUG_ALL_WHOLE_TREE)) == 0 && act && !from_memo && mg.usable && wthread2 != 0xFFFFFFFFu;
         // (two blocks per trip: the tree of a whole batch does not fit the L2, a trip is a memory round trip)
 #pragma nounroll
         for (int cpass = 0; cpass < 2; ++cpass) {   // (a tie between the two lanes' nodes is flagged by scan_push whatever the order)
@@ -898,6 +900,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         //   d_other^2 >= s'_other + |b|^2 - E  >  K1 + |b|^2 + 1.25 E  >=  g + E / 4
         bool clear = act && mg.usable && pd.slot != kNoNode && ((!flag1 && waves_out) || pair) &&
                      (pd.b1 <= (double)K1 + bb + 0.5 * mg.e2);   // (NaN anywhere: false)
+        if (p.dbg_flags & OXHIP_DEBUG_ALL_WHOLE_TREE) clear = false;   // (tests: no screen verdict is trusted)
         clear = clear || from_memo;   // (the memoized answer + the fold over everything committed since = the whole tree)
         {
             // keep the answer current: the first such lane's result holds for the tree of n nodes
@@ -1049,7 +1052,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
         }
         OXHIP_PHASE(4);   // motion check
-        if (STAMP && p.dbg && (p.dbg_flags & 2u) != 0) {   // audit (diagnostic instantiation with OXHIP_DEBUG_FLAGS bit 1): an accepted motion whose end state lies inside one of the first 64 spheres
+        if (STAMP && p.dbg && (p.dbg_flags & OXHIP_DEBUG_AUDIT) != 0) {   // audit (diagnostic instantiation with OXHIP_DEBUG_AUDIT): an accepted motion whose end state lies inside one of the first 64 spheres
             bool inval = false;
             for (uint32_t o = 0; o < ns64; ++o) {
                 double c[D];
@@ -1154,6 +1157,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             }
         }
 
+        if ((p.dbg_flags & OXHIP_DEBUG_ONE_LANE_ROUNDS) != 0 && cut > 1) { cut = 1; stop_after = -1; if (STAMP) ++n_forced; }   // (tests: the rest is re-resolved)
         OXHIP_PHASE(5);   // prefix: cap, goal, conflicts
         // ---- commit lanes [0, cut) in query order
         if (cut > 0) {
@@ -1179,6 +1183,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 const uint64_t hits = hitm & cutm;
                 if (hits != 0 && st.goal_node < 0)
                     st.goal_node = (int32_t)__builtin_amdgcn_readlane((int)idx, __ffsll((unsigned long long)hits) - 1);
+                if (STAMP && ((n ^ (n + (uint32_t)__popcll(okm & cutm))) & ~(uint32_t)(kNRing - 1)) != 0) ++n_wrap;
                 n += (uint32_t)__popcll(okm & cutm);
                 if (lane == 0) lds_post(&sh.committed, n);
             }
@@ -1312,7 +1317,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                 if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid1)) != 0 || extras)
                     ok1 = motion_lanes<DIM>(p, lane, q_near1, qn1, oc, othr, ofilt, ns64);
             }
-            if (STAMP && p.dbg && (p.dbg_flags & 2u) != 0) {   // the same audit for the one-query path
+            if (STAMP && p.dbg && (p.dbg_flags & OXHIP_DEBUG_AUDIT) != 0) {   // the same audit for the one-query path
                 const bool inval1 = lane < ns64 && !(dist2<D>(oc, qn1, DIM) > othr);
                 if (ok1 && __ballot(inval1) != 0 && lane == 0) {
                     atomicAdd((unsigned long long*)&p.dbg[50], 1ull);
@@ -1344,6 +1349,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
                         skip[i] = dup1 ? 1 : 0;
                     }
                     ++n;
+                    if (STAMP && (n & (uint32_t)(kNRing - 1)) == 0) ++n_wrap;
                     if (lane == 0) lds_post(&sh.committed, n);
                     if (dist2<D>(qn1, goal_c, DIM) <= goal_thr) {
                         if (st.goal_node < 0) st.goal_node = (int32_t)i;
@@ -1369,6 +1375,12 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
             atomicMax((unsigned long long*)&p.dbg[46], (unsigned long long)((((uint64_t)clock64() - t_begin) << 16) | (prob & 0xFFFFu)));
             atomicAdd((unsigned long long*)&p.dbg[47], (unsigned long long)((uint64_t)clock64() - t_begin));
             atomicAdd((unsigned long long*)&p.dbg[48], (unsigned long long)n_pair);
+            atomicAdd((unsigned long long*)&p.dbg[54], (unsigned long long)n_amb);
+            atomicAdd((unsigned long long*)&p.dbg[55], (unsigned long long)n_memo);
+            atomicAdd((unsigned long long*)&p.dbg[56], (unsigned long long)n_cut_conflict);
+            atomicAdd((unsigned long long*)&p.dbg[57], (unsigned long long)n_wrap);
+            atomicAdd((unsigned long long*)&p.dbg[58], (unsigned long long)n_pair);
+            atomicAdd((unsigned long long*)&p.dbg[59], (unsigned long long)n_forced);
         }
         if (STAMP && p.dbg && prob == 0) {
             p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict; p.dbg[1] = t_wait; p.dbg[2] = t_work; p.dbg[3] = t_exact; p.dbg[15] = n_tie; p.dbg[11] = n_memo;

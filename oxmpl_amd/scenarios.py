@@ -138,11 +138,11 @@ def make_prm(sc, max_milestones=None, seed=42, stream=0, device=0, timeout=0.0, 
 
 
 def make_batch(sc, n_problems, max_nodes=10000, stop_at_goal=True, seed=42, first_problem_id=0, device=0, kernel=0,
-               planner=0, search_radius=0.0):
+               planner=0, search_radius=0.0, **extra):
     """Build an RRTBatch for a scenario dict and run Planner::setup on every problem."""
     from .capi import RRTBatch
     b = RRTBatch(sc["dim"], sc["bounds"], sc["max_distance"], sc["goal_bias"], n_problems, max_nodes,
-                 sc["lvs_fraction"], stop_at_goal, seed, first_problem_id, device, kernel, planner, search_radius)
+                 sc["lvs_fraction"], stop_at_goal, seed, first_problem_id, device, kernel, planner, search_radius, **extra)
     if sc["spheres"] is not None:
         b.set_spheres(*sc["spheres"])
     if sc["boxes"] is not None:

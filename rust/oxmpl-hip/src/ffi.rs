@@ -8,7 +8,7 @@
 
 use std::os::raw::c_char;
 
-pub const OXHIP_ABI_VERSION: i32 = 1;
+pub const OXHIP_ABI_VERSION: i32 = 2;
 pub const OXHIP_MAX_DIM: usize = 8;
 
 // oxhip_status (mirrors PlanningError, oxmpl/src/base/error.rs:97-108, plus the conditions the reference panics on)
@@ -32,6 +32,9 @@ pub const OXHIP_PLANNER_RRT_STAR: u32 = 2;
 pub const OXHIP_KERNEL_AUTO: u32 = 0;
 pub const OXHIP_SPACE_REAL_VECTOR: u32 = 0;
 pub const OXHIP_SPACE_SE2: u32 = 1;
+// oxhip_goal_sampler: what GoalSampleableRegion::sample_goal draws (goal.rs:35-41)
+pub const OXHIP_GOAL_SAMPLE_CENTRE: u32 = 0;
+pub const OXHIP_GOAL_SAMPLE_UNIFORM_DISC: u32 = 1;
 
 /// `oxhip_rrt_config` (include/oxmpl_hip.h): RRT::new (rrt.rs:75-83) + RealVectorStateSpace::new (rvss.rs:65-100)
 /// + the deterministic termination the reference lacks (rrt.rs:226).
@@ -54,7 +57,9 @@ pub struct OxhipRrtConfig {
     pub planner: u32,
     pub search_radius: f64,
     pub space: u32,
-    pub reserved: u32,
+    pub goal_sampler: u32,
+    pub debug_flags: u32,
+    pub star_pool_share: u32,
 }
 
 /// (field, byte offset, byte size) of `oxhip_rrt_config`
@@ -75,9 +80,11 @@ pub const OXHIP_RRT_CONFIG_LAYOUT: &[(&str, usize, usize)] = &[
     ("planner", 196, 4),
     ("search_radius", 200, 8),
     ("space", 208, 4),
-    ("reserved", 212, 4),
+    ("goal_sampler", 212, 4),
+    ("debug_flags", 216, 4),
+    ("star_pool_share", 220, 4),
 ];
-pub const OXHIP_RRT_CONFIG_SIZE: usize = 216;
+pub const OXHIP_RRT_CONFIG_SIZE: usize = 224;
 
 /// `oxhip_prm_config` (include/oxmpl_hip.h): PRM::new(timeout, connection_radius) (prm.rs:70-78) + the space.
 #[repr(C)]
@@ -216,7 +223,7 @@ mod tests {
     fn repr_c_structs_match_the_layout_tables() {
         check_layout!(OxhipRrtConfig, OXHIP_RRT_CONFIG_LAYOUT, OXHIP_RRT_CONFIG_SIZE,
             [struct_size, dim, bounds, max_distance, goal_bias, lvs_fraction, n_problems, max_nodes, stop_at_goal, kernel,
-             seed, first_problem_id, device, planner, search_radius, space, reserved]);
+             seed, first_problem_id, device, planner, search_radius, space, goal_sampler, debug_flags, star_pool_share]);
         check_layout!(OxhipPrmConfig, OXHIP_PRM_CONFIG_LAYOUT, OXHIP_PRM_CONFIG_SIZE,
             [struct_size, dim, bounds, timeout, connection_radius, lvs_fraction, max_milestones, device, max_samples, seed, stream]);
     }

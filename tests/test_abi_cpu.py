@@ -25,8 +25,8 @@ def test_header_and_binding_export_the_same_symbols(L):
     assert declared == set(capi.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.oxhip_abi_version() == 1
-    assert C.sizeof(capi.Config) == 216  # layout of oxhip_rrt_config on the ABI
+    assert L.oxhip_abi_version() == capi.ABI_VERSION == 2
+    assert C.sizeof(capi.Config) == 224  # layout of oxhip_rrt_config on the ABI
     assert C.sizeof(capi.PrmConfig) == 192  # oxhip_prm_config
 
 

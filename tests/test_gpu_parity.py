@@ -17,11 +17,10 @@ pytestmark = pytest.mark.gpu
 from oxmpl_amd import capi, scenarios  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
 
-# KERNEL_AUTO = what a user gets (the lane-per-query kernel where it exists); KERNEL_PRUNED is an experiment, not in the product build
-KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES, capi.KERNEL_AUTO]
-KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_PRUNED: "pruned",
-         capi.KERNEL_RESIDENT_F32: "resident_f32", capi.KERNEL_LANES: "lanes", capi.KERNEL_AUTO: "auto"}
-SCREENED = (capi.KERNEL_RESIDENT_F32, capi.KERNEL_LANES)   # kernels that count their exact-path events (stamps()[4])
+# KERNEL_AUTO = what a user gets (the lane-per-query kernel where it exists); KERNEL_RESIDENT = the all-binary64 cross-check
+KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_LANES, capi.KERNEL_AUTO]
+KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_LANES: "lanes", capi.KERNEL_AUTO: "auto"}
+SCREENED = (capi.KERNEL_LANES,)   # kernels that count their exact-path events (stamps()[4])
 
 
 def _batch_or_skip(*args, **kw):
@@ -319,7 +318,7 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
             lo = rng.random((nb, dim)) * 6.0 - 1.0
             sc["boxes"] = (lo, lo + rng.random((nb, dim)) * 0.8 + 0.1)
         P = 6
-        if kernel in (capi.KERNEL_RESIDENT, capi.KERNEL_PRUNED, capi.KERNEL_RESIDENT_F32) and dim not in (2, 3):
+        if kernel == capi.KERNEL_RESIDENT and dim not in (2, 3):
             continue  # these resident kernels are instantiated for R^2 / R^3 only
         if kernel == capi.KERNEL_LANES and dim not in (2, 3, 4, 5, 6):
             continue  # the lane-per-query kernel: R^2 .. R^6
@@ -334,12 +333,12 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
 
 @pytest.mark.parametrize("mode", ["product", "whole_tree_path_forced", "whole_tree_path_forced_diagnostic_build"])
 @pytest.mark.parametrize("kernel", [capi.KERNEL_LANES, capi.KERNEL_STREAM], ids=lambda k: KNAME[k])
-def test_fuzz_seed203_r6_case(kernel, mode, monkeypatch):
+def test_fuzz_seed203_r6_case(kernel, mode):
     """The one mismatch tools/fuzz_parity.py found this round (seed 203, committed as a fixture with the obstacle field it drew):
     R^6, 100 spheres, 9 problems grown to 9000 nodes.  In problem 2, iteration 5868, two nodes are 4.5 apart in d2 at
     E = 2.4: the lane-per-query kernel of that build sent the query to its whole-tree path, whose wave-wide motion check read
     sphere 5's threshold across lanes from inside a divergent region -- with the register spilled (R^4..R^6), lane 5 held a
-    stale temporary and an end state inside the sphere was accepted.  OXHIP_DEBUG_FLAGS=1 sends two-lane cases down that
+    stale temporary and an end state inside the sphere was accepted.  debug_flags = DEBUG_PAIR_TO_WHOLE_TREE sends two-lane cases down that
     path again (the product build resolves them in the round), so the path stays covered -- in the product instantiation
     and in the diagnostic one (stamps on), whose audit counts accepted end states that lie inside a sphere."""
     import json
@@ -349,10 +348,11 @@ def test_fuzz_seed203_r6_case(kernel, mode, monkeypatch):
     if no_pair:
         if kernel != capi.KERNEL_LANES:
             pytest.skip("the switch concerns the lane-per-query kernel only")
-        monkeypatch.setenv("OXHIP_DEBUG_FLAGS", "3" if stamped else "1")   # bit 1: the diagnostic build's end-state audit
+    flags = (capi.DEBUG_PAIR_TO_WHOLE_TREE | (capi.DEBUG_AUDIT if stamped else 0)) if no_pair else 0   # AUDIT: the diagnostic build's end-state audit
     dim = d["dim"]
     bounds = [(d["lo"], d["hi"])] * dim
-    gpu = capi.RRTBatch(dim, bounds, d["md"], d["gb"], d["nprob"], d["max_nodes"], d["frac"], d["stop"], d["seed"], d["pid0"], 0, kernel)
+    gpu = capi.RRTBatch(dim, bounds, d["md"], d["gb"], d["nprob"], d["max_nodes"], d["frac"], d["stop"], d["seed"], d["pid0"], 0, kernel,
+                        debug_flags=flags)
     gpu.set_spheres(z["sc"], z["sr"])
     gpu.setup(z["start"], z["goal"], float(z["gr"]))
     if stamped:

@@ -44,9 +44,9 @@ def make_oracle(P, seed, pid, stop=True, max_nodes=None):
     return o
 
 
-def make_gpu(P, n_problems, seed, first_pid, stop=True, max_nodes=None):
+def make_gpu(P, n_problems, seed, first_pid, stop=True, max_nodes=None, **extra):
     g = capi.RRTBatch(P["dim"], P["bounds"], P["max_distance"], P["goal_bias"], n_problems, max_nodes or P["max_nodes"],
-                      P["fraction"], stop, seed, first_pid, 0, DESIGN["kernel"], capi.PLANNER_RRT_STAR, P["search_radius"])
+                      P["fraction"], stop, seed, first_pid, 0, DESIGN["kernel"], capi.PLANNER_RRT_STAR, P["search_radius"], **extra)
     if P["spheres"]:
         g.set_spheres(*params_spheres(P))
     if P["boxes"]:
@@ -194,15 +194,15 @@ def test_rrt_star_argument_validation():
         g.costs(0)          # not an RRT* batch
 
 
-def test_rrt_star_wiring_in_many_rounds(star_golden, star_design, monkeypatch):
+@pytest.mark.parametrize("flags", [0, capi.DEBUG_STAR_TWO_PASS | capi.DEBUG_STAR_ONE_SEGMENT], ids=["default", "two_pass_one_segment"])
+def test_rrt_star_wiring_in_many_rounds(star_golden, star_design, flags):
     """the decoupled design wires, per round, the longest prefix of a problem's pending nodes whose neighbour lists fit its
     pool segment: with the segment cut to its minimum (one list's worst case) and every node a neighbour of every later one,
     a 900-node tree needs hundreds of rounds -- and must come out exactly as in one"""
     if star_design != "decoupled":
         pytest.skip("the pool belongs to the decoupled design")
-    monkeypatch.setenv("OXHIP_STAR_POOL_SHARE", "1")   # clamped up to the node capacity (1024 entries)
     P = dict(star_golden["config2"]["params"], search_radius=float("inf"), max_nodes=900)
-    g = make_gpu(P, 3, 77, 5, stop=False)
+    g = make_gpu(P, 3, 77, 5, stop=False, star_pool_share=1, debug_flags=flags)   # (the share is clamped up to the node capacity: 1024 entries)
     g.solve(400)
     g.solve(10 ** 6)
     c = g.counts()
@@ -233,7 +233,10 @@ def test_rrt_star_full_size_config2(star_golden, star_design):
         cost = g.costs(p)
         assert par[0] == -1 and cost[0] == 0.0
         assert (par[1:] >= 0).all() and (par[1:] < 10000).all()
-        assert (cost[1:] > cost[par[1:]]).all() or (cost[1:] >= cost[par[1:]]).all()   # cost = parent's cost + a distance
+        assert (cost[1:] >= cost[par[1:]]).all()   # cost = parent's cost + a distance (>= : a node may repeat its parent's position)
+        st, _ = g.tree(p)
+        moved = (st[1:] != st[par[1:]]).any(axis=1)
+        assert (cost[1:][moved] > cost[par[1:]][moved]).all()   # ... and strictly more wherever the edge has a length
 
 
 def test_rrt_star_large_row_instantiation(star_golden, star_design):

@@ -10,6 +10,7 @@ OUT=$ROOT/build_variants/$NAME
 mkdir -p $OUT
 cd $ROOT/oxmpl_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function $@ -c rrt_lanes.hip -o $OUT/rrt_lanes.o 2> $OUT/build.err || { cat $OUT/build.err; exit 1; }
-OBJS=$(ls *.o | grep -v rrt_lanes.o)
+# the product library's objects (the Makefile's SRCS), not whatever *.o an older build left behind
+OBJS=$(make -s -pn 2>/dev/null | sed -n 's/^SRCS *:= *//p' | head -1 | tr ' ' '\n' | sed 's/\.hip$/.o/' | grep -v '^rrt_lanes.o$' | tr '\n' ' ')
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $OUT/liboxmpl_hip.so $OBJS $OUT/rrt_lanes.o
 echo built $OUT/liboxmpl_hip.so

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep (not part of the test suite): random spaces, obstacle fields, planner parameters and seeds,
-every planner / kernel against its CPU oracle, bit for bit.  Usage: fuzz_parity.py [seconds] [seed]
-Prints one line per failure (with the parameters to reproduce it) and a summary; exit code 1 on any failure."""
+"""Randomised parity sweep: random spaces, obstacle fields, planner parameters and seeds, every planner / kernel against its
+CPU oracle, bit for bit.  Usage: fuzz_parity.py [seconds] [seed] [planner]
+Prints one line per failure (with the parameters to reproduce it) and a summary; exit code 1 on any failure.
+tests/test_gpu_fuzz.py imports `sweep` and runs a bounded leg of it with fixed seeds inside the -m gpu suite."""
 import json
 import os
 import sys
@@ -12,10 +13,11 @@ import numpy as np  # noqa: E402
 from oxmpl_amd import capi  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
 
-BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-counts, failures = {}, []
+rng = np.random.default_rng(1)   # re-seeded by sweep()
 DUMP_DIR = os.environ.get("FUZZ_DUMP_DIR", "")
+# the lane-per-query kernel's rarely taken paths, forced one or two at a time (oxhip_debug_flag; results identical by construction)
+LANE_FLAGS = [0, 0, 0, 0, capi.DEBUG_PAIR_TO_WHOLE_TREE, capi.DEBUG_ALL_WHOLE_TREE, capi.DEBUG_ONE_LANE_ROUNDS,
+              capi.DEBUG_ALL_WHOLE_TREE | capi.DEBUG_SHORT_MEMO, capi.DEBUG_ONE_LANE_ROUNDS | capi.DEBUG_PAIR_TO_WHOLE_TREE]
 
 
 def bits(a):
@@ -55,18 +57,21 @@ def case_rv(planner):
     radius = float(rng.choice([0.0, 0.05, 0.15, 0.5])) * w
     kernels = [capi.KERNEL_STREAM]
     if planner == capi.PLANNER_RRT and dim in (2, 3):
-        kernels += [capi.KERNEL_RESIDENT, capi.KERNEL_RESIDENT_F32]
+        kernels += [capi.KERNEL_RESIDENT]
     if planner == capi.PLANNER_RRT and 2 <= dim <= 6:
         kernels += [capi.KERNEL_LANES, capi.KERNEL_LANES, capi.KERNEL_AUTO]   # the default path: weighted up
     if planner == capi.PLANNER_RRT_STAR and 2 <= dim <= 6:
         kernels += [capi.KERNEL_AUTO, capi.KERNEL_AUTO]   # RRT*: the decoupled design (rrt_lanes.hip + rrt_star_wire.hip) where it exists
     kernel = int(rng.choice(kernels))
+    flags = int(rng.choice(LANE_FLAGS)) if (kernel in (capi.KERNEL_LANES, capi.KERNEL_AUTO) and planner != capi.PLANNER_RRT_CONNECT) else 0
+    if flags & capi.DEBUG_ALL_WHOLE_TREE:   # every query scans the whole tree with one wave: keep those cases short
+        iters, max_nodes = min(iters, 3000), min(max_nodes, 2500)
     desc = dict(planner=planner, kernel=kernel, dim=dim, lo=lo, hi=hi, md=md, gb=gb, frac=frac, ns=len(sr), nb=len(blo),
-                seed=seed, pid0=pid0, nprob=nprob, max_nodes=max_nodes, iters=iters, stop=stop, radius=radius)
+                seed=seed, pid0=pid0, nprob=nprob, max_nodes=max_nodes, iters=iters, stop=stop, radius=radius, flags=flags)
     if planner == capi.PLANNER_RRT_CONNECT:
         stop = True
     try:
-        g = capi.RRTBatch(dim, bounds, md, gb, nprob, max_nodes, frac, stop, seed, pid0, 0, kernel, planner, radius)
+        g = capi.RRTBatch(dim, bounds, md, gb, nprob, max_nodes, frac, stop, seed, pid0, 0, kernel, planner, radius, debug_flags=flags)
     except capi.OxhipError as e:
         if e.status == capi.ERR_BAD_ARG:
             return None
@@ -218,26 +223,38 @@ def case_se2():
 CASES = [("rrt", lambda: case_rv(capi.PLANNER_RRT)), ("rrt", lambda: case_rv(capi.PLANNER_RRT)),
          ("rrt_connect", lambda: case_rv(capi.PLANNER_RRT_CONNECT)), ("rrt_star", lambda: case_rv(capi.PLANNER_RRT_STAR)),
          ("prm", case_prm), ("se2_connect", case_se2)]
-if len(sys.argv) > 3:   # third argument: only this planner's cases (e.g. rrt_star)
-    CASES = [c for c in CASES if c[0] == sys.argv[3]]
-t0 = time.perf_counter()
-i = 0
-slowest = 0.0
-while time.perf_counter() - t0 < BUDGET:
-    name, fn = CASES[i % len(CASES)]
-    i += 1
-    t_case = time.perf_counter()
-    r = fn()
-    if time.perf_counter() - t_case > slowest:
-        slowest = time.perf_counter() - t_case
-        print("slowest case so far: %s %.2f s" % (name, slowest), flush=True)
-    if r is None:
-        continue
-    counts[name] = counts.get(name, 0) + 1
-    if r is not True:
-        failures.append(r)
-        print("FAIL", json.dumps({k: (v if not isinstance(v, tuple) else list(v)) for k, v in r.items()}), flush=True)
-    if i % 50 == 0:
-        print("progress", counts, "failures", len(failures), flush=True)
-print(json.dumps({"seconds": BUDGET, "cases": counts, "failures": len(failures)}))
-sys.exit(1 if failures else 0)
+
+
+def sweep(budget_s, seed, only=None, verbose=True):
+    """run random cases for `budget_s` seconds from `seed`; returns (cases per planner, list of failures)"""
+    global rng
+    rng = np.random.default_rng(seed)
+    cases = [c for c in CASES if only is None or c[0] == only]
+    counts, failures = {}, []
+    t0 = time.perf_counter()
+    i = 0
+    slowest = 0.0
+    while time.perf_counter() - t0 < budget_s:
+        name, fn = cases[i % len(cases)]
+        i += 1
+        t_case = time.perf_counter()
+        r = fn()
+        if verbose and time.perf_counter() - t_case > slowest:
+            slowest = time.perf_counter() - t_case
+            print("slowest case so far: %s %.2f s" % (name, slowest), flush=True)
+        if r is None:
+            continue
+        counts[name] = counts.get(name, 0) + 1
+        if r is not True:
+            failures.append(r)
+            print("FAIL", json.dumps({k: (v if not isinstance(v, tuple) else list(v)) for k, v in r.items()}), flush=True)
+        if verbose and i % 50 == 0:
+            print("progress", counts, "failures", len(failures), flush=True)
+    return counts, failures
+
+
+if __name__ == "__main__":
+    BUDGET = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    counts, failures = sweep(BUDGET, int(sys.argv[2]) if len(sys.argv) > 2 else 1, sys.argv[3] if len(sys.argv) > 3 else None)
+    print(json.dumps({"seconds": BUDGET, "cases": counts, "failures": len(failures)}))
+    sys.exit(1 if failures else 0)

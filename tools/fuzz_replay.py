@@ -16,7 +16,7 @@ kernel = int(sys.argv[2]) if len(sys.argv) > 2 else d["kernel"]
 dim, planner = d["dim"], d["planner"]
 bounds = [(d["lo"], d["hi"])] * dim
 g = capi.RRTBatch(dim, bounds, d["md"], d["gb"], d["nprob"], d["max_nodes"], d["frac"], d["stop"], d["seed"], d["pid0"], 0, kernel,
-                  planner, d["radius"])
+                  planner, d["radius"], debug_flags=d.get("flags", 0))
 if len(z["sr"]):
     g.set_spheres(z["sc"], z["sr"])
 if len(z["blo"]):

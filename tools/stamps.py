@@ -22,5 +22,3 @@ print("   of which combine %.0f cyc/iter; exact-path events %d of %d" % (int(s[3
 print("scanner waves: wait   ", " ".join("%6.0f" % (int(v) / iters) for v in s[16:24]))
 print("               scan   ", " ".join("%6.0f" % (int(v) / iters) for v in s[24:32]))
 print("scanner wave 5 per query: pre (absorb, q loads) %.0f  scan %.0f  reduce+publish %.0f cyc" % (int(s[8]) / iters, int(s[9]) / iters, int(s[10]) / iters))
-if KERN == capi.KERNEL_PRUNED:
-    print("pruned: builds %d (%.0f cyc each), extra rows scanned by wave 5 per query %.2f" % (int(s[5]), int(s[6]) / max(1, int(s[5])), int(s[11]) / iters))
