@@ -3,8 +3,9 @@ oxhip_rrt_config.debug_flags and run over the golden matrix (README scene, the r
 product instantiation AND in the stamped one whose counters prove the path was really taken.
 
   DEBUG_ALL_WHOLE_TREE    no screen verdict is trusted: every query takes the whole-tree path (one query at a time, the wave
-                          scanning the binary64 tree) unless the memoized whole-tree answer applies --
-                          with goal_bias > 0 the goal centre is drawn again and again, so the memo is hit all the time
+                          scanning the binary64 tree) unless the memoized whole-tree answer applies (the
+                          memo holds the LAST whole-tree query: with goal_bias 0.5 a goal-centre query follows another one a
+                          quarter of the time -- test_goal_bias_half_memo_is_reused_and_refreshed)
   DEBUG_SHORT_MEMO        ... and the memo expires after 8 inserts, so it is refreshed (whole-tree path) and reused in turns
   DEBUG_ONE_LANE_ROUNDS   a round commits one lane: every other lane is re-resolved against the grown tree (the ring fold picks
                           the new nodes up), i.e. a conflict cut every round
@@ -65,7 +66,7 @@ def _check_counters(name, s, iterations):
     if "whole_tree" in name and "pair" not in name:
         assert int(s[W_WHOLE_TREE]) + int(s[W_MEMO]) >= 0.95 * iterations, (int(s[W_WHOLE_TREE]), int(s[W_MEMO]), iterations)
         assert int(s[W_WHOLE_TREE]) > 0
-    if "one_lane" in name:
+    if "one_lane" in name and "whole_tree" not in name:   # (with no verdict trusted a round never gets past its first lane anyway)
         assert int(s[W_FORCED_CUT]) > 0
 
 
@@ -92,10 +93,7 @@ def test_golden_fixtures_under_forced_paths(golden, key, name, stamped):
         assert list(parents[:m]) == run["first_parents"]
         assert [[hexf(v) for v in row] for row in gpu.path(0)] == run["path"]
         if stamped:
-            s = gpu.stamps()
-            _check_counters(name, s, run["iterations"])
-            if "whole_tree" in name and "pair" not in name and sc["goal_bias"] > 0 and "short" not in name:
-                assert int(s[W_MEMO]) > 0   # the goal centre, drawn 5 % of the time, is answered from the memo
+            _check_counters(name, gpu.stamps(), run["iterations"])
         gpu.close()
 
 
@@ -144,7 +142,7 @@ def test_goal_bias_half_memo_is_reused_and_refreshed():
         c = gpu.counts()
         for p in range(P):
             _same(gpu, p, planners[p], c)
-        assert int(s[W_MEMO]) > 0.2 * P * iters, int(s[W_MEMO])
+        assert int(s[W_MEMO]) > (0.03 if flags & capi.DEBUG_SHORT_MEMO else 0.1) * P * iters, int(s[W_MEMO])
         gpu.close()
 
 
