@@ -44,7 +44,7 @@ if ROOT not in sys.path:
 N_NODES = 10000
 BYTES_PER_ITER = N_NODES * 3 * 8          # B(n) = n * d * 8
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
-KNAME = {1: "stream", 2: "resident", 5: "lanes"}
+KNAME = {1: "stream", 2: "resident", 5: "lanes", 6: "cells"}
 ROWS_PER_ITERATION = 10240 // 64          # register rows (64 nodes each) one query is screened against
 CUS = 256
 

@@ -110,9 +110,12 @@ typedef enum oxhip_kernel_kind {
                                    (R^2 / R^3, <= 10,240 nodes): no binary32 anywhere -- the cross-check of the screened kernels */
     OXHIP_KERNEL_RETIRED_3 = 3, /* (ABI 1: box-pruned resident scan, an experiment) -- OXHIP_ERR_BAD_ARG since ABI 2 */
     OXHIP_KERNEL_RETIRED_4 = 4, /* (ABI 1: binary32 screen + lane-group resolver, round 1's default) -- OXHIP_ERR_BAD_ARG since ABI 2 */
-    OXHIP_KERNEL_LANES = 5      /* resident + binary32 screen with a lane-per-query resolver: up to 64 iterations are
+    OXHIP_KERNEL_LANES = 5,     /* resident + binary32 screen with a lane-per-query resolver: up to 64 iterations are
                                    resolved side by side and committed as the longest prefix that keeps the reference's
                                    sequential semantics (rrt_lanes.hip); same results bit for bit */
+    OXHIP_KERNEL_CELLS = 6      /* one WAVE per problem; nearest neighbour through an exact grid of cells (per-cell node lists in
+                                   HBM / L2, the 3^D cells around a query first, further shells when they cannot rule out the rest),
+                                   lane-per-query as above (rrt_cells.hip; R^2 / R^3, any tree size); same results bit for bit */
 } oxhip_kernel_kind;
 
 /* RRT::new(max_distance, goal_bias) (rrt.rs:75-83) + RealVectorStateSpace::new(dim, bounds)
@@ -142,6 +145,9 @@ typedef struct oxhip_rrt_config {
     uint32_t star_pool_share;           /* RRT*, decoupled design: neighbour-list pool entries per problem (16 B each, + 4.5 B of chunk
                                            store); 0 = default: 64 x tree capacity, bounded so that the whole batch stays below 24 GB.
                                            The size bounds memory, never results: lists that do not fit are wired in further rounds */
+    uint32_t frozen_split;              /* OXHIP_KERNEL_CELLS, solve(freeze = 1): waves a problem's frozen iterations are divided over
+                                           (1 .. 8; 0 = automatic: enough to fill the chip).  Results do not depend on it */
+    uint32_t reserved;                  /* 0 */
 } oxhip_rrt_config;
 
 typedef struct oxhip_rrt_batch oxhip_rrt_batch;

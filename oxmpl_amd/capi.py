@@ -18,7 +18,7 @@ OK, ERR_TIMEOUT, ERR_NO_SOLUTION_FOUND, ERR_PLANNER_UNINITIALISED = 0, 1, 2, 3
 ERR_INVALID_START_STATE, ERR_UNSAMPLED_STATE_SPACE = 4, 5
 ERR_BAD_ARG, ERR_UNBOUNDED, ERR_ZERO_VOLUME, ERR_CAPACITY, ERR_HIP, ERR_NO_DEVICE = 16, 17, 18, 19, 32, 33
 STOP_NONE, STOP_GOAL, STOP_ITERATIONS, STOP_NODES, STOP_TIMEOUT = -1, 0, 1, 2, 3
-KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT, KERNEL_LANES = 0, 1, 2, 5   # (3 and 4 were retired with ABI version 2)
+KERNEL_AUTO, KERNEL_STREAM, KERNEL_RESIDENT, KERNEL_LANES, KERNEL_CELLS = 0, 1, 2, 5, 6   # (3 and 4 were retired with ABI version 2)
 GOAL_SAMPLE_CENTRE, GOAL_SAMPLE_UNIFORM_DISC = 0, 1
 # oxhip_debug_flag: test-only switches that force rarely taken code paths (results identical by construction)
 DEBUG_PAIR_TO_WHOLE_TREE, DEBUG_AUDIT, DEBUG_ALL_WHOLE_TREE, DEBUG_ONE_LANE_ROUNDS, DEBUG_SHORT_MEMO = 1, 2, 4, 8, 16
@@ -53,6 +53,7 @@ class Config(C.Structure):
         ("kernel", C.c_uint32), ("seed", C.c_uint64), ("first_problem_id", C.c_uint64),
         ("device", C.c_int32), ("planner", C.c_uint32), ("search_radius", C.c_double),
         ("space", C.c_uint32), ("goal_sampler", C.c_uint32), ("debug_flags", C.c_uint32), ("star_pool_share", C.c_uint32),
+        ("frozen_split", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -186,7 +187,7 @@ class RRTBatch:
     def __init__(self, dim, bounds, max_distance, goal_bias, n_problems, max_nodes=10000,
                  lvs_fraction=0.05, stop_at_goal=True, seed=0, first_problem_id=0, device=0,
                  kernel=KERNEL_AUTO, planner=PLANNER_RRT, search_radius=0.0, space=SPACE_REAL_VECTOR,
-                 goal_sampler=GOAL_SAMPLE_CENTRE, debug_flags=0, star_pool_share=0):
+                 goal_sampler=GOAL_SAMPLE_CENTRE, debug_flags=0, star_pool_share=0, frozen_split=0):
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
         cfg.dim = dim
@@ -203,6 +204,7 @@ class RRTBatch:
         cfg.search_radius = search_radius
         cfg.space = space
         cfg.goal_sampler, cfg.debug_flags, cfg.star_pool_share = goal_sampler, debug_flags, star_pool_share
+        cfg.frozen_split = frozen_split
         self.planner = planner
         self.dim, self.n_problems, self.max_nodes = dim, n_problems, max_nodes
         self._h = C.c_void_p()

@@ -30,6 +30,11 @@ struct oxhip_rrt_batch {
     DevBuf<double> tree, goal_c, goal_thr, goal_r, sph_c, sph_thr, sph_filt, box_lo, box_hi;
     std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
     bool filt_dirty = true;
+    DevBuf<float> cell_node;        // rrt_cells.hip: per-cell node lists, grid descriptors, accumulators of split frozen launches
+    DevBuf<uint32_t> cell_head;
+    DevBuf<CellMeta> cell_meta;
+    DevBuf<CellAcc> cell_acc;
+    DevBuf<uint64_t> cell_part_pos;
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
@@ -103,10 +108,13 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_BAD_ARG, "goal_bias outside [0,1] (rand Bernoulli::new would fail)");
     if (!(cfg->max_distance > 0.0) || !std::isfinite(cfg->max_distance))
         return fail(OXHIP_ERR_BAD_ARG, "max_distance must be finite and > 0");
-    if (cfg->kernel > OXHIP_KERNEL_LANES) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
+    if (cfg->kernel > OXHIP_KERNEL_CELLS) return fail(OXHIP_ERR_BAD_ARG, "unknown kernel kind");
     if (cfg->kernel == OXHIP_KERNEL_RETIRED_3 || cfg->kernel == OXHIP_KERNEL_RETIRED_4)
         return fail(OXHIP_ERR_BAD_ARG, "kernel kinds 3 (box-pruned scan) and 4 (lane-group resolver) were retired in ABI version 2");
     if (cfg->planner > OXHIP_PLANNER_RRT_STAR) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
+    if (cfg->frozen_split > 8) return fail(OXHIP_ERR_BAD_ARG, "frozen_split must be 0 (automatic) or 1 .. 8");
+    if (cfg->kernel == OXHIP_KERNEL_CELLS && cfg->planner != OXHIP_PLANNER_RRT)
+        return fail(OXHIP_ERR_BAD_ARG, "the cell-grid kernel runs the RRT planner");
     if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
         return fail(OXHIP_ERR_BAD_ARG, "RRTConnect runs on the stream kernel only");
     // RRT*: KERNEL_STREAM = rrt_star.hip (one workgroup per problem, everything in one kernel); KERNEL_LANES = the decoupled
@@ -257,6 +265,34 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (cfg->planner != OXHIP_PLANNER_RRT) kind = b->star_wired ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO)
         kind = lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
+    if (kind == OXHIP_KERNEL_CELLS) {
+        if (!cells_supported(dim, cap)) {
+            oxhip_rrt_batch_destroy(b);
+            return fail(OXHIP_ERR_BAD_ARG, "cell-grid kernel: R^2 / R^3 trees of at most 2^20 nodes");
+        }
+        dp.cell_level_max = cells_level_max(dim, cap);
+        dp.cell_heads = 1u << (dim * dp.cell_level_max);
+        if (dp.cell_heads < 64u) dp.cell_heads = 64u;
+        // frozen launches: a problem's iterations are independent, so they are divided over enough waves to fill the chip
+        // (256 CUs x 8 waves of this kernel's register budget)
+        uint32_t split = cfg->frozen_split;
+        if (split == 0) { split = (2048u + P - 1u) / P; if (split > 8u) split = 8u; if (split < 1u) split = 1u; }
+        dp.cells_split = split;
+        hipError_t e2 = b->cell_node.alloc((size_t)P * cap * 4);
+        if (e2 == hipSuccess) e2 = b->cell_head.alloc((size_t)P * dp.cell_heads);
+        if (e2 == hipSuccess) e2 = b->cell_meta.alloc(P);
+        if (e2 == hipSuccess) e2 = b->cell_acc.alloc(P);
+        if (e2 == hipSuccess) e2 = b->cell_part_pos.alloc((size_t)P * 8);
+        if (e2 == hipSuccess) e2 = hipMemset(b->cell_meta.p, 0, (size_t)P * sizeof(CellMeta));
+        if (e2 == hipSuccess) e2 = hipMemset(b->cell_acc.p, 0, (size_t)P * sizeof(CellAcc));
+        if (e2 != hipSuccess) {
+            std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e2);
+            oxhip_rrt_batch_destroy(b);
+            return fail(OXHIP_ERR_HIP, msg);
+        }
+        dp.cell_node = b->cell_node.p; dp.cell_head = b->cell_head.p; dp.cell_meta = b->cell_meta.p;
+        dp.cell_acc = b->cell_acc.p; dp.cell_part_pos = b->cell_part_pos.p;
+    }
     if (kind == OXHIP_KERNEL_LANES && !lanes_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
         return fail(OXHIP_ERR_BAD_ARG, "resident (lane-per-query) kernel does not support this (dim, max_nodes)");
@@ -393,6 +429,7 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
                              (size_t)P * dim, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemsetAsync(b->skip.p, 0, (size_t)P * cap, b->stream));
     if (b->shadow_state.p) HIP_TRY(hipMemsetAsync(b->shadow_state.p, 0, (size_t)P * 2 * sizeof(uint32_t), b->stream));  // shadows start over
+    if (b->cell_meta.p) HIP_TRY(hipMemsetAsync(b->cell_meta.p, 0, (size_t)P * sizeof(CellMeta), b->stream));              // the grids too
     std::vector<int32_t> minus1(P, -1);
     HIP_TRY(hipMemcpy2DAsync(b->parent.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
                              sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
@@ -497,6 +534,7 @@ int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const dou
     HIP_TRY(hipMemcpyAsync(b->skip.p + (size_t)problem * cap, skip.data(), n, hipMemcpyHostToDevice, b->stream));
     if (b->shadow_state.p)   // this problem's fl32 shadow starts over
         HIP_TRY(hipMemsetAsync(b->shadow_state.p + 2 * (size_t)problem, 0, 2 * sizeof(uint32_t), b->stream));
+    if (b->cell_meta.p) HIP_TRY(hipMemsetAsync(b->cell_meta.p + problem, 0, sizeof(CellMeta), b->stream));   // ... and its cell grid
     std::vector<ProblemState> states;
     if ((st = read_states(b, states)) != OXHIP_OK) return st;
     states[problem].n_nodes = n;
@@ -617,6 +655,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
             if ((st = wire_new_nodes(b)) != OXHIP_OK) return st;
         }
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) launch_rrt_star(b->dp, b->stream);
+        else if (kind == OXHIP_KERNEL_CELLS) launch_rrt_cells(b->dp, b->stream);
         else if (kind == OXHIP_KERNEL_LANES) launch_rrt_lanes(b->dp, b->stream);
         else if (kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
         else launch_rrt_stream(b->dp, b->stream);

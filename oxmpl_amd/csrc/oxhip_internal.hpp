@@ -55,6 +55,11 @@ void launch_rrt_resident(const DevParams& p, hipStream_t stream);
 bool lanes_supported(uint32_t dim, uint32_t cap);
 void launch_rrt_lanes(const DevParams& p, hipStream_t stream);
 
+// rrt_cells.hip: one wave per problem, nearest neighbour through an exact cell grid (R^2, R^3)
+bool cells_supported(uint32_t dim, uint32_t cap);
+uint32_t cells_level_max(uint32_t dim, uint32_t cap);
+void launch_rrt_cells(const DevParams& p, hipStream_t stream);
+
 // prm_kernels.hip: PRM roadmap construction / query (prm.rs)
 struct PrmState {            // persists in HBM between launches
     uint64_t draws;          // u64 words consumed from the ChaCha12 stream

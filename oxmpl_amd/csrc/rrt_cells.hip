@@ -1,0 +1,1127 @@
+// rrt_cells.hip -- RRT grow loop, ONE WAVE PER PLANNING PROBLEM, nearest neighbour through an exact cell grid (R^2, R^3).
+//
+// rrt_lanes.hip scans every node for every query (the reference's loop, rrt.rs:187-196, as a register-resident screen) and
+// spends a whole CU on one problem.  This kernel does less work and needs no CU-wide choreography:
+//
+// * lane j of the wave IS query jr + j (as in rrt_lanes.hip's resolver): sample, nearest neighbour, steer, motion check,
+//   commit of the longest prefix that keeps the reference's sequential semantics -- all inside one wave, no hand-off to
+//   other waves, no workgroup barrier after the launch's first.
+// * nearest neighbour: the nodes live in a uniform grid of cubic cells over the bounding box of the bounds, the goal centre
+//   and the tree -- G = 2^floor(log2(n) / D) cells along the longest side, ~1 to 2^D nodes per cell, re-gridded whenever n
+//   reaches the next power -- as per-cell linked lists in HBM / L2: heads[cell] and node i = (tx, ty, tz, next), its position
+//   in CELL UNITS as binary32.  A lane walks the 3^D cells around its query's cell (9 chains at a time, their loads in
+//   flight together), keeps the smallest and the second smallest binary32 squared distance, and accepts the smallest iff
+//     d1 + A < d2 - A        (no other visited node can be nearer or tie:  A = sqrt(D) delta, delta the bound on any stored
+//                             coordinate's and the query's error in cell units: Gmax 2^-23 + the measured clamping error)
+//     d1 + A < lb            (no unvisited node can: lb = distance from the query to the nearest open face of the block)
+//   then the winner's distance, steer, motion check, tree and checksum are binary64 from the binary64 node, exactly as in
+//   every other kernel.  When lb fails (a query deep inside an obstacle, a sparse tree) the WAVE searches the next shells of
+//   cells for that one query; when the margin fails (1e-4 of queries) the query takes the whole-tree path: the reference's
+//   d2 scan / literal loop over the binary64 tree.  Trees of up to 1,024 nodes are scanned node by node (uniform addresses).
+// * inserting a node is one atomic exchange on its cell's head: the grid is always current, there is no "nodes committed
+//   since the snapshot" to fold in, no rebuild, no sorted order to maintain.
+// * with inserts suppressed (the steady measurement) the queries of a launch are independent: a problem's launch is cut into
+//   `split` contiguous parts, one wave each (stream positions of the part starts from cells_prepare_kernel), whose checksum
+//   polynomials and counters are summed with atomics; the last part to finish writes the problem's state.
+//
+// Everything that enters a result is binary64 in the reference's evaluation order; the grid only names a candidate.
+// Replaces the loop body of RRT::solve, oxmpl/src/geometric/planners/rrt.rs:170-225.
+#include "oxhip_internal.hpp"
+#include "rrt_device.hpp"
+#include "rrt_resident_common.hpp"
+#include "lane_query_common.hpp"
+
+namespace oxhip {
+
+constexpr uint32_t kCellEnd = 0xFFFFFFFFu;
+#ifndef OXHIP_CELLS_BRUTE
+#define OXHIP_CELLS_BRUTE 1024
+#endif
+constexpr uint32_t kBruteMax = OXHIP_CELLS_BRUTE;   // trees up to this size: every node, by index
+constexpr int kCellsWaves = 4;                       // waves (= problems, or parts of problems) per workgroup
+constexpr int kMaxShell = 6;                         // the cooperative search gives up beyond this ring (-> whole-tree path)
+
+typedef float cfloat4 __attribute__((ext_vector_type(4)));
+
+struct CellGrid {   // wave-uniform
+    double lo[3], inv_h;
+    uint32_t G[3];
+    uint32_t level, regrid_at;
+    float top[3];        // largest binary32 below G[k]: stored coordinates are clamped to [0, top]
+    double delta_node;   // bound on |stored - true| of any node coordinate, cell units
+};
+
+template <int DIM>
+struct CellsWaveLds {
+    uint32_t rng_buf[16][64];
+    double q[DIM][64];            // the round's queries, slot (jr + lane) & 63
+    uint64_t pos_after[64];
+    double newn[DIM][64];         // the round's would-be new nodes, by rank
+    float newn32[64][4];          // ... as the dot-product pre-screen holds them: fl32(x - c0), fl32(|.|^2)
+    float obs32_thr[64];          // the sphere pre-filter's thresholds (they carry this problem's magnitude bound)
+};
+template <int DIM>
+struct CellsShared {
+    double obs[DIM + 2][64];      // first 64 spheres: centre, validity threshold, filter threshold
+    float obs32[64][4];           // fl32(centre - c0), fl32(|.|^2)
+    CellsWaveLds<DIM> w[kCellsWaves];
+};
+
+__device__ __forceinline__ uint32_t cells_level(uint32_t n, int dim, uint32_t level_max) {
+    if (n <= kBruteMax) return 0u;
+    const uint32_t l = (31u - (uint32_t)__clz((int)n)) / (uint32_t)dim;
+    return l < level_max ? l : level_max;
+}
+
+template <int DIM>
+__device__ __forceinline__ void grid_load(const CellMeta& m, CellGrid& g) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.lo[k] = unid(m.lo[k]);
+        g.G[k] = uni(m.G[k]);
+        g.top[k] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)g.G[k]) - 1u);
+    }
+    g.inv_h = unid(m.inv_h);
+    g.level = uni(m.level);
+    g.regrid_at = uni(m.regrid_at);
+    g.delta_node = (double)__builtin_bit_cast(float, uni(__builtin_bit_cast(uint32_t, m.delta_node)));
+}
+
+// position of x in cell units as the grid stores it (binary32, clamped into the grid), its cell, and the error made
+template <int DIM>
+__device__ __forceinline__ uint32_t cell_place(const CellGrid& g, const double x[DIM], float tf[3], double& err) {
+    uint32_t c[3] = {0u, 0u, 0u};
+    err = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < DIM) {
+            const double t = (x[k] - g.lo[k]) * g.inv_h;
+            float f = (float)t;
+            f = fminf(fmaxf(f, 0.0f), g.top[k]);   // (NaN -> 0; never expected: nodes are finite)
+            tf[k] = f;
+            err = fmax(err, fabs((double)f - t));
+            c[k] = (uint32_t)f;
+        } else {
+            tf[k] = 0.0f;
+        }
+    }
+    return (c[2] * g.G[1] + c[1]) * g.G[0] + c[0];
+}
+
+// (Re)build the grid of problem `prob` for its n nodes: one wave.  Chooses the level from n, the box from the bounds, the
+// goal centre and the nodes; links every node that is not a skipped duplicate.  Returns the largest |fl32(x - c0)| bits.
+template <int DIM>
+__device__ __forceinline__ void cells_build(const DevParams& p, uint32_t prob, uint32_t n, uint32_t lane, const double* c0, CellGrid& g,
+                                            uint32_t& mabs_bits) {
+    const size_t cap = p.cap;
+    const double* tree = p.tree + (size_t)prob * DIM * cap;
+    const uint8_t* skip = p.skip + (size_t)prob * cap;
+    uint32_t* heads = p.cell_head + (size_t)prob * p.cell_heads;
+    cfloat4* nodes = reinterpret_cast<cfloat4*>(p.cell_node) + (size_t)prob * cap;
+    double lo[DIM], hi[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const double gc = p.goal_c[(size_t)prob * DIM + k];
+        lo[k] = fmin(p.lo[k], gc);
+        hi[k] = fmax(p.hi[k], gc);
+    }
+    uint32_t mab = 0;
+    for (uint32_t i = lane; i < n; i += 64) {
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) {
+            const double x = tree[(size_t)k * cap + i];
+            lo[k] = fmin(lo[k], x);
+            hi[k] = fmax(hi[k], x);
+            const uint32_t ab = lf32_bits((float)(x - c0[k])) & 0x7FFFFFFFu;
+            mab = ab > mab ? ab : mab;
+        }
+    }
+    mabs_bits = wave_max_u32(mab);
+    double wmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        lo[k] = wave_min_f64(lo[k]);
+        hi[k] = -wave_min_f64(-hi[k]);
+        wmax = fmax(wmax, hi[k] - lo[k]);
+    }
+    g.level = cells_level(n, DIM, p.cell_level_max);
+    const uint32_t G = 1u << g.level;
+    g.inv_h = (double)G / wmax;   // (wmax > 0: create() refuses lo >= hi)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < DIM) {
+            g.lo[k] = lo[k];
+            uint32_t gk = (uint32_t)((hi[k] - lo[k]) * g.inv_h) + 1u;
+            g.G[k] = gk < G ? gk : G;
+        } else {
+            g.lo[k] = 0.0;
+            g.G[k] = 1u;
+        }
+        g.top[k] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)g.G[k]) - 1u);
+    }
+    g.regrid_at = n <= kBruteMax ? kBruteMax + 1u
+                                 : (g.level < p.cell_level_max ? (1u << ((uint32_t)DIM * (g.level + 1u))) : 0xFFFFFFFFu);
+    const uint32_t nc = g.G[0] * g.G[1] * g.G[2];
+    for (uint32_t c = lane; c < nc; c += 64) heads[c] = kCellEnd;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    double derr = 0.0;
+    for (uint32_t i = lane; i < n; i += 64) {
+        double x[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) x[k] = tree[(size_t)k * cap + i];
+        float tf[3];
+        double err;
+        const uint32_t cell = cell_place<DIM>(g, x, tf, err);
+        cfloat4 nd;
+        if (skip[i] == 0) {
+            derr = fmax(derr, err);
+            const uint32_t old = g.level == 0 ? kCellEnd
+                                              : __hip_atomic_exchange(&heads[cell], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nd = cfloat4{tf[0], tf[1], tf[2], lbits_f32(old)};
+        } else {   // a duplicate of a lower-index node can never win (strict '<', rrt.rs:192): not in the grid
+            nd = cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), lbits_f32(kCellEnd)};
+        }
+        nodes[i] = nd;
+    }
+    derr = -wave_min_f64(-derr);
+    g.delta_node = (double)f32_up(derr * (1.0 + 1e-9) + 1e-30);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+}
+
+template <int DIM>
+__device__ __forceinline__ void grid_store(CellMeta& m, const CellGrid& g, uint32_t n, uint32_t mabs_bits, uint32_t lane) {
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { m.lo[k] = g.lo[k]; m.G[k] = g.G[k]; }
+        m.inv_h = g.inv_h;
+        m.level = g.level;
+        m.regrid_at = g.regrid_at;
+        m.n_grid = n;
+        m.delta_node = (float)g.delta_node;   // (exact: it came from a float)
+        m.mabs_bits = mabs_bits;
+        m.valid = 1u;
+    }
+}
+
+// Lane-parallel sampling of m <= 64 consecutive queries (rrt.rs:177-184 + rvss.rs:233-249; sample_batch of
+// rrt_resident_common.hpp with this kernel's ring).  STORE = false only advances the stream position (the fast-forward of
+// cells_prepare_kernel).  Returns false, nothing written, when a range draw was rejected or the window is too short.
+template <int DIM, bool STORE>
+__device__ __forceinline__ bool cells_sample(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane,
+                                             CellsWaveLds<DIM>* sh, uint32_t js) {
+    const uint64_t win_lo = rng.base_blk * 8;
+    const uint64_t pos0 = rng.pos;
+    if (pos0 < win_lo || pos0 + (uint64_t)m * (1 + DIM) > win_lo + 512) return false;
+    const uint32_t rel0 = (uint32_t)(pos0 - win_lo);
+    const bool act = lane < m;
+    const bool always_goal = p.p_int == ~0ull;
+    auto word = [&](uint32_t rel) -> uint64_t {
+        const uint32_t a = rel0 + rel, bl = a >> 3, w = (a & 7u) * 2u;
+        return ((uint64_t)rng.buf[w + 1][bl] << 32) | rng.buf[w][bl];
+    };
+    uint64_t goal_mask = always_goal ? ~0ull : 0ull;
+    uint32_t off = 0;
+    if (!always_goal) {
+        const uint64_t below = below_mask(lane);
+        for (uint32_t round = 0; round <= m; ++round) {
+            off = act ? (1u + DIM) * lane - (uint32_t)DIM * (uint32_t)__popcll(goal_mask & below) : 0u;
+            const uint64_t now = __ballot(act && word(off) < p.p_int);
+            if (now == goal_mask) break;
+            goal_mask = now;
+        }
+    }
+    const bool goal = (goal_mask >> lane) & 1ull;
+    double q[DIM];
+    bool redraw = false;
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        const uint64_t bits = (word(act && !goal ? off + 1u + (uint32_t)k : 0u) >> 12) | 0x3FF0000000000000ull;
+        const double v01 = __longlong_as_double((long long)bits) - 1.0;
+        double res = v01 * p.scale[k];
+        res = res + p.lo[k];
+        redraw = redraw || !(res < p.hi[k]);
+        q[k] = goal ? goal_c[k] : res;
+    }
+    if (__ballot(act && !goal && redraw) != 0) return false;
+    const uint32_t cnt = always_goal ? 0u : (goal ? 1u : 1u + (uint32_t)DIM);
+    if (STORE && act) {
+        const uint32_t slot = (js + lane) & 63u;
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) sh->q[k][slot] = q[k];
+        sh->pos_after[slot] = pos0 + off + cnt;
+    }
+    rng.pos = pos0 + (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), (int)(m - 1));
+    return true;
+}
+
+// draw (STORE) or skip the queries [js, js + m): window refill, the lane-parallel sampler, the sequential fallback
+template <int DIM, bool STORE>
+__device__ __forceinline__ void cells_sample_block(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane,
+                                                   CellsWaveLds<DIM>* sh, uint32_t js) {
+    const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + DIM) + 64;
+    if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
+        rng.base_blk = uni64(rng.pos >> 3);
+        uint32_t o[16];
+        chacha12_block(rng.seed, rng.base_blk + lane, rng.stream, o);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
+    }
+    if (!cells_sample<DIM, STORE>(rng, p, goal_c, m, lane, sh, js)) {
+        for (uint32_t b = 0; b < m; ++b) {   // (never expected) a redraw, or a batch past the window: one by one
+            double qn[DIM];
+            sample_state<DIM, false>(rng, p, DIM, goal_c, qn);
+            if (STORE && lane == 0) {
+                const uint32_t slot = (js + b) & 63u;
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) sh->q[k][slot] = qn[k];
+                sh->pos_after[slot] = rng.pos;
+            }
+        }
+    }
+}
+
+// smallest / second smallest screen value and the node holding the smallest
+struct Top2 {
+    float s1, s2;
+    uint32_t i1;
+};
+__device__ __forceinline__ void top2_push(Top2& t, float s, uint32_t i) {
+    const bool lt = s < t.s1;
+    t.i1 = lt ? i : t.i1;
+    float m;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(s), "v"(t.s1), "v"(t.s2));   // the second smallest of three with s1 <= s2
+    t.s2 = m;
+    vmin_f32(t.s1, s);
+}
+template <int DIM>
+__device__ __forceinline__ float cell_s(const cfloat4& nd, const float (&tq)[3]) {
+    const float e0 = nd[0] - tq[0];
+    float s = e0 * e0;
+    const float e1 = nd[1] - tq[1];
+    s = __builtin_fmaf(e1, e1, s);
+    if (DIM >= 3) {
+        const float e2 = nd[2] - tq[2];
+        s = __builtin_fmaf(e2, e2, s);
+    }
+    return s;
+}
+
+// distance (cell units) from tq to the nearest OPEN face of the block of cells [cq - r, cq + r] (+inf: the block is the grid)
+template <int DIM>
+__device__ __forceinline__ double block_lb(const CellGrid& g, const float (&tq)[3], const uint32_t (&cq)[3], uint32_t r) {
+    double lb = __builtin_inf();
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+        if (cq[k] > r) lb = fmin(lb, (double)tq[k] - (double)(cq[k] - r));                     // cells below the block exist
+        if (cq[k] + r + 1u < g.G[k]) lb = fmin(lb, (double)(cq[k] + r + 1u) - (double)tq[k]);    // cells above
+    }
+    return lb;
+}
+
+// the acceptance test: 0 = proven (the smallest is the unique nearest node), 1 = search the next shell, 2 = ambiguous
+__device__ __forceinline__ int cells_verdict(const Top2& t, double lb, double A) {
+    if (!(t.s1 < __builtin_inff())) return lb < __builtin_inf() ? 1 : 2;   // nothing found yet
+    const double d1 = sqrt((double)t.s1) * (1.0 + 0x1p-20) + A;
+    const double d2 = sqrt((double)t.s2) * (1.0 - 0x1p-20) - A;
+    if (!(d1 < d2)) return 2;
+    if (!(d1 < lb * (1.0 - 0x1p-20))) return 1;
+    return 0;
+}
+
+template <int DIM, bool STAMP>
+__global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p) {
+    constexpr int D = DIM;
+    __shared__ CellsShared<DIM> shared;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = uni(tid >> 6), lane = tid & 63;
+    // problems are dealt to the XCDs round-robin (workgroup w runs on XCD w % 8) and all parts of a problem stay on one XCD:
+    // they share its L2 copy of the grid
+    const uint32_t split = p.freeze ? p.cells_split : 1u;
+    const uint32_t xcd = blockIdx.x & 7u, unit = (blockIdx.x >> 3) * (uint32_t)kCellsWaves + wave;
+    const uint32_t prob = (unit / split) * 8u + xcd, part = unit % split;
+
+    const uint32_t ns64 = p.n_spheres < 64 ? p.n_spheres : 64;
+    const uint32_t nobs = p.n_spheres + p.n_boxes;
+    const bool extras = nobs > ns64;
+    double c0[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) c0[k] = 0.5 * p.lo[k] + 0.5 * p.hi[k];
+    // sphere `lane`: registers (the wave-wide motion check of the whole-tree path) and LDS (the lane-parallel checks)
+    double oc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) oc[k] = lane < ns64 ? p.sph_c[(size_t)k * p.n_spheres + lane] : 0.0;
+    const double othr = lane < ns64 ? p.sph_thr[lane] : -1.0;
+    const double ofilt = lane < ns64 ? p.sph_filt[lane] : -1.0;
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) shared.obs[k][lane] = oc[k];
+        shared.obs[D][lane] = othr;
+        shared.obs[D + 1][lane] = ofilt;
+    }
+    const bool live = prob < p.n_problems;
+    const ProblemState st0 = p.state[live ? prob : 0u];
+    CellsWaveLds<DIM>* sh = &shared.w[wave];
+    CellMeta& meta = p.cell_meta[live ? prob : 0u];
+    CellGrid grid;
+    grid_load<DIM>(meta, grid);
+    LMargins mg;
+    {
+        double h = (double)lbits_f32(uni(meta.mabs_bits)) * (1.0 + 0x1p-23);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            h = fmax(h, fmax(fabs(p.lo[k] - c0[k]), fabs(p.hi[k] - c0[k])));
+            h = fmax(h, fabs(p.goal_c[(size_t)(live ? prob : 0u) * DIM + k] - c0[k]));
+        }
+        h = unid(h) * 1.001;   // interpolation rounding over any chain of inserts
+        const double u = 0x1p-24;
+        mg.usable = h < 1e15 && fabs(c0[0]) < 1e300;
+        mg.e2 = 2.0 * (u * h * h * (double)(D * (3 * D + 9)) * 1.0001 + 1e-290);
+        // the spheres for the binary32 pre-filter of the motion check: same error model with H_f = max(H, |centre - c0|)
+        double hs = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) hs = fmax(hs, lane < ns64 ? fabs(oc[k] - c0[k]) : 0.0);
+        const double hf = fmax(h, wave_max_f64pos(hs));
+        const double ef = 2.0 * (u * hf * hf * (double)(D * (3 * D + 9)) * 1.0001 + 1e-290);
+        if (wave == 0) {
+            double sq = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const float f = (float)(oc[k] - c0[k]);
+                shared.obs32[lane][k] = f;
+                sq += (double)f * (double)f;
+            }
+            shared.obs32[lane][D] = (float)sq;
+        }
+        // a sphere is cleared when s' + |m|^2 > thr: thr = (filter threshold + 2 E_f), rounded up (and two ulps more for the sum)
+        float thr = (float)((ofilt + ef) * (1.0 + 0x1p-21));
+        thr = thr + fabsf(thr) * 0x1p-22f;
+        sh->obs32_thr[lane] = (lane < ns64 && mg.usable && hf < 1e15 && ofilt >= 0.0) ? thr : (lane < ns64 ? __builtin_inff() : -1.0f);
+    }
+    __syncthreads();   // the launch's only barrier: the obstacle tables are in LDS
+    if (!live) return;
+    if (p.stop_at_goal && st0.goal_node >= 0) return;
+
+    const size_t cap = p.cap;
+    double* tree = p.tree + (size_t)prob * DIM * cap;
+    int32_t* parent = p.parent + (size_t)prob * cap;
+    uint8_t* skip = p.skip + (size_t)prob * cap;
+    uint32_t* heads = p.cell_head + (size_t)prob * p.cell_heads;
+    cfloat4* nodes = reinterpret_cast<cfloat4*>(p.cell_node) + (size_t)prob * cap;
+    double goal_c[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
+    const double goal_thr = p.goal_thr[prob];
+
+    // this wave's share of the launch: iterations [j_lo, j_hi) of the problem's budget
+    const uint32_t budget_all = (uint32_t)p.budget;
+    uint32_t j_lo = 0, j_hi = budget_all;
+    uint64_t pos_start = st0.draws;
+    if (split > 1) {
+        const uint32_t rounds = (budget_all + 63u) / 64u;
+        j_lo = (uint32_t)(((uint64_t)rounds * part) / split) * 64u;
+        j_hi = (uint32_t)(((uint64_t)rounds * (part + 1u)) / split) * 64u;
+        if (j_hi > budget_all) j_hi = budget_all;
+        pos_start = p.cell_part_pos[(size_t)prob * 8u + part];
+    }
+    const uint32_t budget = j_hi - j_lo;
+
+    // P^lane for the batched checksum (H <- H P^m + sum_j g_j P^(m-1-j)); P^64 for a full batch
+    uint64_t pw = 1;
+    {
+        uint64_t base = kFnvPrime;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            if ((lane >> b) & 1u) pw *= base;
+            base *= base;
+        }
+    }
+    const uint64_t pw64 = uni64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pw >> 32), 63) << 32 |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pw, 63)) * kFnvPrime);
+
+    RngWindow rng;
+    rng.init(sh->rng_buf, p.seed, p.first_problem_id + prob, pos_start);
+    ProblemState st = st0;
+    if (split > 1) { st.checksum = 0; st.accepted = 0; st.iterations = 0; }   // this part's own sums (combined at the end)
+    uint64_t draws_done = pos_start;
+    uint32_t n = st.n_nodes;
+    uint32_t mabs_bits = uni(meta.mabs_bits);
+    uint32_t jr = 0, js = 0;
+    int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
+    uint64_t n_rounds = 0, n_lanes = 0, n_amb = 0, n_expand = 0, n_cut_conflict = 0, n_tie = 0, n_memo = 0, n_forced = 0, n_regrid = 0, n_steps = 0;
+    uint64_t t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_pm = 0;
+    const uint64_t t_begin = STAMP ? (uint64_t)clock64() : 0;
+#define OXHIP_CPHASE(IDX) do { if (STAMP) { const uint64_t now_ = (uint64_t)clock64(); t_ph[IDX] += now_ - t_pm; t_pm = now_; } } while (0)
+    // the last whole-tree answer: valid while the tree has not grown
+    uint32_t memo_n = 0xFFFFFFFFu, memo_idx = kNoNode;
+    double memo_g = 0.0, memo_q[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) memo_q[k] = 0.0;
+    typedef double ldouble4 __attribute__((ext_vector_type(4)));
+
+    while (true) {
+        if (jr >= budget) { stop = 1; break; }
+        if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
+        if (!p.freeze && n >= grid.regrid_at) {   // the tree outgrew its grid: the next finer one
+            cells_build<DIM>(p, prob, n, lane, c0, grid, mabs_bits);
+            if (STAMP) ++n_regrid;
+        }
+        uint32_t m = budget - jr < 64u ? budget - jr : 64u;
+        if (js < jr + m) {   // draw the queries this round still lacks (rrt.rs:177-184): they depend on the stream only
+            cells_sample_block<DIM, true>(rng, p, goal_c, jr + m - js, lane, sh, js);
+            js = jr + m;
+        }
+        if (STAMP) { ++n_rounds; n_lanes += m; t_pm = (uint64_t)clock64(); }
+        const bool act = lane < m;
+        const uint32_t slot = (jr + (act ? lane : 0u)) & 63u;
+        double q[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) q[k] = sh->q[k][slot];
+        const uint64_t pos_after_l = sh->pos_after[slot];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's own earlier stores (tree, grid nodes) have landed
+
+        // ---- nearest neighbour (rrt.rs:187-196): a binary32 screen over the cells around the query names one candidate
+        Top2 t2{__builtin_inff(), __builtin_inff(), kNoNode};
+        float tq[3] = {0.0f, 0.0f, 0.0f};
+        uint32_t cq[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            tq[k] = (float)((q[k] - grid.lo[k]) * grid.inv_h);
+            const float fl = floorf(tq[k]);
+            cq[k] = fl > 0.0f ? (fl < (float)grid.G[k] ? (uint32_t)fl : grid.G[k] - 1u) : 0u;   // (NaN -> 0)
+        }
+        const uint32_t gmax = grid.G[0] > grid.G[1] ? (grid.G[0] > grid.G[2] ? grid.G[0] : grid.G[2]) : (grid.G[1] > grid.G[2] ? grid.G[1] : grid.G[2]);
+        const double A = sqrt((double)D) * (grid.delta_node + (double)gmax * 0x1p-23) * 1.01 + 1e-30;
+        int verdict;   // 0 proven, 2 ambiguous (whole-tree path)
+        bool from_memo = act && memo_n == n;
+#pragma unroll
+        for (int k = 0; k < D; ++k) from_memo = from_memo && __double_as_longlong(q[k]) == __double_as_longlong(memo_q[k]);
+        if (grid.level == 0) {
+            // every node, by index: wave-uniform addresses (one cache line serves all lanes)
+            for (uint32_t i0 = 0; i0 < n; i0 += 4) {
+                cfloat4 nd[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) nd[t] = nodes[uni(i0 + (uint32_t)t < n ? i0 + (uint32_t)t : 0u)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (i0 + (uint32_t)t < n) top2_push(t2, cell_s<DIM>(nd[t], tq), i0 + (uint32_t)t);
+            }
+            if (STAMP) n_steps += n;
+            verdict = cells_verdict(t2, __builtin_inf(), A);
+        } else {
+            constexpr int NR = DIM == 3 ? 9 : 3;   // rows of the 3^D block: the cells of a row are the x-neighbours
+            uint32_t hd[NR][3];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int dy = r % 3 - 1, dz = r / 3 - 1;
+                const int cy = (int)cq[1] + dy, cz = (int)cq[2] + (DIM == 3 ? dz : 0);
+                const bool row_ok = act && cy >= 0 && cy < (int)grid.G[1] && cz >= 0 && cz < (int)grid.G[2];
+                const uint32_t base = ((uint32_t)(row_ok ? cz : 0) * grid.G[1] + (uint32_t)(row_ok ? cy : 0)) * grid.G[0];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int cx = (int)cq[0] + c - 1;
+                    const bool ok = row_ok && cx >= 0 && cx < (int)grid.G[0];
+                    const uint32_t v = __hip_atomic_load(&heads[base + (uint32_t)(ok ? cx : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hd[r][c] = ok ? v : kCellEnd;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                uint32_t cur[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) cur[r] = hd[r][c];
+                for (;;) {
+                    bool any = false;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) any = any || cur[r] != kCellEnd;
+                    if (__ballot(any) == 0) break;
+                    if (STAMP) ++n_steps;
+                    cfloat4 nd[NR];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) nd[r] = nodes[cur[r] != kCellEnd ? cur[r] : 0u];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const bool on = cur[r] != kCellEnd;
+                        if (__ballot(on) != 0) {
+                            const float s = on ? cell_s<DIM>(nd[r], tq) : __builtin_inff();
+                            top2_push(t2, s, cur[r]);
+                            cur[r] = on ? lf32_bits(nd[r][3]) : kCellEnd;
+                        }
+                    }
+                }
+            }
+            verdict = cells_verdict(t2, block_lb<DIM>(grid, tq, cq, 1u), A);
+            // ---- a lane whose block cannot rule out the cells beyond it: the WAVE searches the next shells for that query
+            uint64_t needm = __ballot(act && !from_memo && verdict == 1);
+            while (needm != 0) {
+                const int jl = __ffsll((unsigned long long)needm) - 1;
+                needm &= needm - 1;
+                if (STAMP) ++n_expand;
+                float tqj[3];
+                uint32_t cqj[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    tqj[k] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(tq[k]), jl));
+                    cqj[k] = (uint32_t)__builtin_amdgcn_readlane((int)cq[k], jl);
+                }
+                Top2 tj{lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(t2.s1), jl)),
+                        lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(t2.s2), jl)),
+                        (uint32_t)__builtin_amdgcn_readlane((int)t2.i1, jl)};
+                int vj = 1;
+                for (uint32_t r = 2; vj == 1; ++r) {
+                    if (r > (uint32_t)kMaxShell) { vj = 2; break; }   // far too sparse here: the whole-tree path settles it
+                    const uint32_t side = 2u * r + 1u, total = DIM == 3 ? side * side * side : side * side;
+                    Top2 tl{__builtin_inff(), __builtin_inff(), kNoNode};
+                    for (uint32_t t = lane; t < total; t += 64) {
+                        const int dx = (int)(t % side) - (int)r, dy = (int)((t / side) % side) - (int)r;
+                        const int dz = DIM == 3 ? (int)(t / (side * side)) - (int)r : 0;
+                        const int ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy, az = dz < 0 ? -dz : dz;
+                        const int cheb = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
+                        const int cx = (int)cqj[0] + dx, cy = (int)cqj[1] + dy, cz = (int)cqj[2] + dz;
+                        if (cheb != (int)r || cx < 0 || cy < 0 || cz < 0 || cx >= (int)grid.G[0] || cy >= (int)grid.G[1] || cz >= (int)grid.G[2]) continue;
+                        uint32_t cur = __hip_atomic_load(&heads[((uint32_t)cz * grid.G[1] + (uint32_t)cy) * grid.G[0] + (uint32_t)cx],
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        while (cur != kCellEnd) {
+                            const cfloat4 nd = nodes[cur];
+                            top2_push(tl, cell_s<DIM>(nd, tqj), cur);
+                            cur = lf32_bits(nd[3]);
+                        }
+                    }
+                    // the shell's two smallest over the wave (binary32 values >= +0 order like their bit patterns)
+                    const uint32_t m1 = wave_min_u32(lf32_bits(tl.s1));
+                    const uint64_t winm = __ballot(lf32_bits(tl.s1) == m1);
+                    const uint32_t m2 = __popcll(winm) >= 2 ? m1 : wave_min_u32(lf32_bits(tl.s1) == m1 ? lf32_bits(tl.s2) : lf32_bits(tl.s1));
+                    const uint32_t wi = (uint32_t)__builtin_amdgcn_readlane((int)tl.i1, __ffsll((unsigned long long)winm) - 1);
+                    top2_push(tj, lbits_f32(m1), wi);
+                    top2_push(tj, lbits_f32(m2), kNoNode);   // (only its value matters; i1 stays the holder of the smallest)
+                    vj = cells_verdict(tj, block_lb<DIM>(grid, tqj, cqj, r), A);
+                }
+                if (lane == (uint32_t)jl) { t2 = tj; verdict = vj; }
+            }
+        }
+        OXHIP_CPHASE(0);   // the screen
+        // ---- the candidate in binary64, exactly as the reference computes it
+        uint32_t nearest = (act && verdict == 0) ? t2.i1 : kNoNode;
+        double q_near[D];
+        {
+            const uint32_t ni = nearest == kNoNode ? 0u : nearest;
+#pragma unroll
+            for (int k = 0; k < D; ++k) q_near[k] = tree[(size_t)k * cap + ni];
+        }
+        double g = nearest == kNoNode ? __builtin_inf() : dist2<D>(q_near, q, DIM);
+        // the screen's own claim, checked on the binary64 value (turns a corrupted record into an unproven lane)
+        bool clear = nearest != kNoNode && fabs(sqrt(g) * grid.inv_h - sqrt((double)t2.s1)) <= A + sqrt((double)t2.s1) * 0x1p-19 + 1e-30;
+        if (p.dbg_flags & OXHIP_DEBUG_ALL_WHOLE_TREE) clear = false;   // (tests: no screen verdict is trusted)
+        if (from_memo) {   // the whole-tree path's last answer, for this very query on this very tree
+            nearest = memo_idx;
+            g = memo_g;
+#pragma unroll
+            for (int k = 0; k < D; ++k) q_near[k] = tree[(size_t)k * cap + memo_idx];
+            clear = true;
+        }
+        if (STAMP) n_memo += (uint64_t)__popcll(__ballot(from_memo));
+        const bool amb = act && !clear;
+        const uint32_t hb = hi32(g) + 1;
+        double qn[D], mid[D];
+        steer<DIM>(p, false, g, q_near, q, qn);
+        const bool dup = g == 0.0;
+        OXHIP_CPHASE(1);   // candidate + steer
+        // this lane's query as the dot-product pre-screens see it: Q = -2 fl32(q - c0), |b|^2
+        float Qf[D];
+        double bb = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const float bk = (float)(q[k] - c0[k]);
+            Qf[k] = -2.0f * bk;
+            bb += (double)bk * (double)bk;
+        }
+        // ---- check_motion (rrt.rs:90-116): the midpoint filter names the spheres the segment can touch at all ...
+        bool bad = false;
+        if (nobs > 0) {
+            lerp<DIM>(q_near, qn, 0.5, mid, DIM);
+            float Qm[D], mm = 0.0f;
+            {
+                double mmd = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const float mk = (float)(mid[k] - c0[k]);
+                    Qm[k] = -2.0f * mk;
+                    mmd += (double)mk * (double)mk;
+                }
+                mm = (float)(mmd * (1.0 - 0x1p-22));   // rounded down: errs towards "maybe"
+            }
+            uint32_t maybe_lo = 0, maybe_hi = 0;
+            for (uint32_t o0 = 0; o0 < ns64; o0 += 8) {
+                uint32_t b8 = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float* of = shared.obs32[o0 + t];
+                    float sp = of[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sp = __builtin_fmaf(of[k], Qm[k], sp);
+                    screen_bit(b8, sp + mm, sh->obs32_thr[o0 + t]);   // !(sp + mm > thr)  (NaN / inf threshold: maybe; -1: no sphere)
+                }
+                const uint32_t bits = rev8(b8);
+                if (o0 < 32) maybe_lo |= bits << o0; else maybe_hi |= bits << (o0 - 32);
+            }
+            if (!mg.usable) { maybe_lo = 0xFFFFFFFFu; maybe_hi = 0xFFFFFFFFu; }
+            {
+                uint64_t rem = ((uint64_t)maybe_hi << 32) | maybe_lo;
+                if (ns64 < 64) rem &= (1ull << ns64) - 1ull;
+                uint64_t keep = 0;
+                while (__ballot(rem != 0) != 0) {
+                    const bool has = rem != 0;
+                    const uint32_t o = has ? (uint32_t)(__ffsll((unsigned long long)rem) - 1) : 0u;
+                    double c[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) c[k] = shared.obs[k][o];
+                    if (has && sphere_maybe_hit<DIM>(c, shared.obs[D + 1][o], mid)) keep |= 1ull << o;
+                    rem &= rem - 1;
+                }
+                maybe_lo = (uint32_t)keep;
+                maybe_hi = (uint32_t)(keep >> 32);
+            }
+            const uint64_t maybe = ((uint64_t)maybe_hi << 32) | maybe_lo;
+            OXHIP_CPHASE(2);   // sphere filter
+            const bool need = act && !amb && (maybe != 0 || extras);
+            if (__ballot(need) != 0) {
+                // ... and every lane steps through its own motion against just those (is_valid is pure: testing all states
+                // equals the reference's first-invalid early exit)
+                const double dist = sqrt(dist2<DIM>(q_near, qn, DIM));
+                const uint32_t nsteps = num_steps_u32(dist, p.res);
+                const uint32_t steps_l = need ? (nsteps <= 1 ? 1u : nsteps) : 0u;
+                const uint32_t smax = wave_max_u32(steps_l);
+                const double dn = (double)nsteps;
+                for (uint32_t s = 1; s <= smax && s != 0; ++s) {
+                    const bool on = s <= steps_l;
+                    double x[D];
+                    {
+                        const double t = (double)s / dn;
+                        double xi[D];
+                        lerp<DIM>(q_near, qn, t, xi, DIM);
+#pragma unroll
+                        for (int k = 0; k < D; ++k) x[k] = nsteps <= 1 ? qn[k] : xi[k];   // num_steps <= 1: is_valid(to) only
+                    }
+                    uint64_t rem = on ? maybe : 0ull;
+                    while (__ballot(rem != 0) != 0) {
+                        const bool has = rem != 0;
+                        const uint32_t o = has ? (uint32_t)(__ffsll((unsigned long long)rem) - 1) : 0u;
+                        double c[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) c[k] = shared.obs[k][o];
+                        bad = bad || (has && !(dist2<D>(c, x, DIM) > shared.obs[D][o]));
+                        rem &= rem - 1;
+                    }
+                    for (uint32_t jx = ns64; jx < nobs; ++jx) bad = bad || (on && obstacle_hit<DIM>(p, DIM, x, jx));
+                }
+            }
+        }
+        OXHIP_CPHASE(3);   // motion check
+        const bool ok = act && !bad;
+        const bool ins = !p.freeze;
+        float nf_a[D], nf_cc;
+        {
+            double sq = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                nf_a[k] = (float)(qn[k] - c0[k]);
+                sq += (double)nf_a[k] * (double)nf_a[k];
+            }
+            nf_cc = (float)sq;
+        }
+
+        // ---- the prefix this round may commit
+        uint32_t cut = m;
+        int32_t stop_after = -1;
+        const uint64_t ambm = __ballot(amb);
+        if (ambm != 0) cut = (uint32_t)(__ffsll((unsigned long long)ambm) - 1);
+        const uint64_t okm = __ballot(ok);
+        uint64_t hitm = 0;
+        if (ins) {
+            // node cap: query j is processed only while the tree has room (checked before any draw of the iteration)
+            const uint64_t capm = __ballot(act && n + (uint32_t)__popcll(okm & below_mask(lane)) >= p.max_nodes);
+            if (capm != 0) {
+                const uint32_t c = (uint32_t)(__ffsll((unsigned long long)capm) - 1);
+                if (c <= cut) { cut = c; stop_after = 2; }
+            }
+            hitm = __ballot(ok && dist2<D>(qn, goal_c, DIM) <= goal_thr);
+            if (p.stop_at_goal && hitm != 0) {
+                const uint32_t c = (uint32_t)__ffsll((unsigned long long)hitm);   // first hit lane + 1
+                if (c <= cut) { cut = c; stop_after = 0; }
+            }
+            // a node accepted earlier in the round that is (nearly) as close to a later query as that query's nearest node
+            // changes that query's result: the prefix ends before the first such query (binary32 first: the new node of lane i
+            // matters to lane j only if d2 <= g_j (1 + 2^-19)).  The would-be new nodes are staged by rank.
+            const uint64_t newm = __ballot(ok && !dup);
+            const uint32_t rank = (uint32_t)__popcll(newm & below_mask(lane));
+            const float thr_c = (mg.usable && g < 1e300) ? f32_up(g * (1.0 + 0x1p-19) - bb + mg.e2) : __builtin_inff();
+            if (ok && !dup) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) { sh->newn32[rank][k] = nf_a[k]; sh->newn[k][rank] = qn[k]; }
+                sh->newn32[rank][D] = nf_cc;
+            }
+            const uint32_t n_new = (uint32_t)__popcll(newm);
+            for (uint32_t t0 = 0; t0 < n_new; t0 += 8) {
+                const uint32_t ahead = rank < n_new ? rank : n_new;
+                const uint32_t t_hi = ahead > t0 ? (ahead - t0 < 8u ? ahead - t0 : 8u) : 0u;
+                const uint32_t valid = (act && lane < cut) ? ((1u << t_hi) - 1u) : 0u;
+                uint32_t bits = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float* nf = sh->newn32[(t0 + (uint32_t)t) & 63u];
+                    float sp = nf[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sp = __builtin_fmaf(nf[k], Qf[k], sp);
+                    screen_bit(bits, sp, thr_c);
+                }
+                const uint32_t lookm = rev8(bits) & valid;
+                if (__ballot(lookm != 0) != 0) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (__ballot((lookm >> t) & 1u) != 0) {
+                            const uint32_t sl = (t0 + (uint32_t)t) & 63u;
+                            double ca[D];
+#pragma unroll
+                            for (int k = 0; k < D; ++k) ca[k] = sh->newn[k][sl];
+                            const uint64_t cm = __ballot(((lookm >> t) & 1u) != 0 && hi32(dist2<D>(ca, q, DIM)) <= hb);
+                            if (cm != 0) {
+                                const uint32_t c = (uint32_t)(__ffsll((unsigned long long)cm) - 1);
+                                if (c < cut) { cut = c; stop_after = -1; if (STAMP) ++n_cut_conflict; }
+                            }
+                        }
+                    }
+                }
+                const uint64_t behind = newm & ~first_n_mask(cut);
+                if (t0 + 8 >= n_new - (uint32_t)__popcll(behind)) break;
+            }
+        }
+        if ((p.dbg_flags & OXHIP_DEBUG_ONE_LANE_ROUNDS) != 0 && cut > 1) { cut = 1; stop_after = -1; if (STAMP) ++n_forced; }
+        OXHIP_CPHASE(4);   // prefix: cap, goal, conflicts
+        // ---- commit lanes [0, cut) in query order
+        if (cut > 0) {
+            const uint64_t cutm = first_n_mask(cut);
+            const bool mine = lane < cut;
+            if (ins) {
+                const uint32_t idx = n + (uint32_t)__popcll(okm & below_mask(lane));
+                if (mine && ok) {
+                    // insert (rrt.rs:213-217): the tree, and -- unless it repeats its nearest node's position, which the strict
+                    // '<' of rrt.rs:192 can never prefer -- its cell's list
+#pragma unroll
+                    for (int k = 0; k < D; ++k) tree[(size_t)k * cap + idx] = qn[k];
+                    parent[idx] = (int32_t)nearest;
+                    skip[idx] = dup ? 1 : 0;
+                }
+                {
+                    float tf[3];
+                    double err;
+                    const uint32_t cell = cell_place<DIM>(grid, qn, tf, err);
+                    const bool link = mine && ok && !dup;
+                    uint32_t old = kCellEnd;
+                    if (link && grid.level != 0) old = __hip_atomic_exchange(&heads[cell], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (mine && ok)
+                        nodes[idx] = link ? cfloat4{tf[0], tf[1], tf[2], lbits_f32(old)}
+                                          : cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), lbits_f32(kCellEnd)};
+                    const double e = -wave_min_f64(link ? -err : 0.0);
+                    if (e > grid.delta_node) grid.delta_node = (double)f32_up(e * (1.0 + 1e-9));
+                    uint32_t mab = 0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) { const uint32_t ab = lf32_bits(nf_a[k]) & 0x7FFFFFFFu; mab = ab > mab ? ab : mab; }
+                    mab = wave_max_u32(mine && ok ? mab : 0u);
+                    mabs_bits = mab > mabs_bits ? mab : mabs_bits;
+                }
+                // goal test (rrt.rs:220-223): the first hit in query order
+                const uint64_t hits = hitm & cutm;
+                if (hits != 0 && st.goal_node < 0)
+                    st.goal_node = (int32_t)__builtin_amdgcn_readlane((int)idx, __ffsll((unsigned long long)hits) - 1);
+                n += (uint32_t)__popcll(okm & cutm);
+            }
+            // checksum: H <- H P^cut + sum_{j < cut} g_j P^(cut-1-j)
+            {
+                const uint64_t gd = iter_digest<D>(nearest, qn, DIM, ok);
+                const int src = mine ? (int)(cut - 1u - lane) : 0;
+                const uint64_t w = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pw >> 32), src, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)pw, src, 64);
+                const uint64_t sum = wave_sum_u64(mine ? gd * w : 0ull);
+                const uint64_t pc = cut >= 64u ? pw64
+                                               : uni64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pw >> 32), (int)cut) << 32) |
+                                                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pw, (int)cut));
+                st.checksum = st.checksum * pc + sum;
+            }
+            st.iterations += cut;
+            st.accepted += (uint64_t)__popcll(okm & cutm);
+            draws_done = uni64((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pos_after_l, (int)(cut - 1u)) |
+                               ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_l >> 32), (int)(cut - 1u)) << 32));
+            jr += cut;
+        }
+        OXHIP_CPHASE(5);   // commit
+        if (stop_after >= 0) { stop = stop_after; break; }
+        if (cut == m || ambm == 0 || (uint32_t)(__ffsll((unsigned long long)ambm) - 1) != cut) continue;
+
+        // ---- the lane at `cut` is ambiguous: that one query over the WHOLE binary64 tree (the path of rrt_lanes.hip).  First
+        //      by squared distances, the wave striding over the nodes: if exactly one node is within a rounding of the
+        //      minimum, it is the reference's nearest node (sqrt is monotone).  Only a genuine near-tie -- two d2 that may
+        //      share a correctly rounded root -- takes the reference's literal loop (post-sqrt compare, lowest index).
+        if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
+        {
+            if (STAMP) ++n_amb;
+            const uint32_t slot1 = jr & 63u;
+            double q1[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) q1[k] = unid(sh->q[k][slot1]);
+            bool same_q = memo_n == n;
+#pragma unroll
+            for (int k = 0; k < D; ++k) same_q = same_q && __double_as_longlong(q1[k]) == __double_as_longlong(memo_q[k]);
+            double gmin = memo_g;
+            uint32_t memo_hit_idx = memo_idx;
+            bool tie = false;
+            if (!same_q) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores to the tree have landed (same CU)
+                Scan ps{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
+                for (uint32_t i0 = 4u * lane; i0 < n; i0 += 1024u) {
+                    uint32_t sk4[4], il[4];
+                    double d16[4][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t ib = i0 + 256u * (uint32_t)t;
+                        il[t] = ib < n ? ib : 0u;   // (rows are padded to cap >= n rounded up to 1024)
+                        sk4[t] = *reinterpret_cast<const uint32_t*>(skip + il[t]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        ldouble4 ck[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) ck[t] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il[t]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double df = ck[t][r] - q1[k];
+                                const double sq = df * df;
+                                d16[t][r] = k == 0 ? sq : d16[t][r] + sq;   // the reference's summation order
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t i = i0 + 256u * (uint32_t)t + (uint32_t)r;
+                            if (i < n && ((sk4[t] >> (8 * r)) & 0xFFu) == 0) scan_push(ps, d16[t][r], i);   // ascending within the lane: ties keep the lower index
+                        }
+                    }
+                }
+                gmin = wave_min_f64(ps.b1);
+                const uint32_t hbw = hi32(gmin) + 1;
+                const uint64_t nearm = __ballot(ps.slot != kNoNode && hi32(ps.b1) <= hbw);
+                tie = __popcll(nearm) != 1 || __ballot(ps.h2 <= hbw) != 0;
+                memo_hit_idx = tie ? kNoNode : (uint32_t)__builtin_amdgcn_readlane((int)ps.slot, __ffsll((unsigned long long)(nearm | (1ull << 63))) - 1);
+                if (!tie) {
+                    memo_n = n; memo_g = gmin; memo_idx = memo_hit_idx;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) memo_q[k] = q1[k];
+                }
+            } else if (STAMP) ++n_memo;
+            uint32_t nearest1;
+            double qn1[D], q_near1[D];
+            bool dup1;
+            if (!tie) {
+                nearest1 = memo_hit_idx;
+#pragma unroll
+                for (int k = 0; k < D; ++k) q_near1[k] = unid(tree[(size_t)k * cap + nearest1]);
+                dup1 = gmin == 0.0;
+                steer<DIM>(p, false, gmin, q_near1, q1, qn1);
+            } else {
+                if (STAMP) ++n_tie;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                Exact e{__builtin_inf(), kNoNode};
+                for (uint32_t i = lane; i < n; i += 64) {
+                    double c[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k)
+                        c[k] = __hip_atomic_load(&tree[(size_t)k * cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const double d = sqrt(dist2<D>(c, q1, DIM));
+                    if (d < e.dist) { e.dist = d; e.idx = i; }
+                }
+                e = exact_wave_reduce(e);
+                nearest1 = uni(e.idx);
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+                    q_near1[k] = unid(__hip_atomic_load(&tree[(size_t)k * cap + nearest1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const double dist1 = unid(e.dist);
+                dup1 = dist1 == 0.0;
+                steer<DIM>(p, true, dist1, q_near1, q1, qn1);
+            }
+            bool ok1 = true;
+            if (nobs > 0) {
+                double mid1[D];
+                lerp<DIM>(q_near1, qn1, 0.5, mid1, DIM);
+                if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid1)) != 0 || extras)
+                    ok1 = motion_lanes<DIM>(p, lane, q_near1, qn1, oc, othr, ofilt, ns64);
+            }
+            st.checksum = uni64(chk_push(st.checksum, iter_digest<D>(nearest1, qn1, DIM, ok1)));
+            st.iterations++;
+            draws_done = uni64(sh->pos_after[slot1]);
+            bool hit1 = false;
+            if (ok1) {
+                st.accepted++;
+                if (!p.freeze) {
+                    const uint32_t i = n;
+                    float tf[3];
+                    double err;
+                    const uint32_t cell = cell_place<DIM>(grid, qn1, tf, err);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) tree[(size_t)k * cap + i] = qn1[k];
+                        parent[i] = (int32_t)nearest1;
+                        skip[i] = dup1 ? 1 : 0;
+                        uint32_t old = kCellEnd;
+                        if (!dup1 && grid.level != 0) old = __hip_atomic_exchange(&heads[cell], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        nodes[i] = dup1 ? cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), lbits_f32(kCellEnd)}
+                                        : cfloat4{tf[0], tf[1], tf[2], lbits_f32(old)};
+                    }
+                    if (!dup1 && err > grid.delta_node) grid.delta_node = (double)f32_up(err * (1.0 + 1e-9));
+                    {
+                        uint32_t mab = 0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) { const uint32_t ab = lf32_bits((float)(qn1[k] - c0[k])) & 0x7FFFFFFFu; mab = ab > mab ? ab : mab; }
+                        mabs_bits = mab > mabs_bits ? mab : mabs_bits;
+                    }
+                    ++n;
+                    if (dist2<D>(qn1, goal_c, DIM) <= goal_thr) {
+                        if (st.goal_node < 0) st.goal_node = (int32_t)i;
+                        hit1 = true;
+                    }
+                }
+            }
+            jr += 1;
+            if (hit1 && p.stop_at_goal) { stop = 0; break; }
+        }
+    }
+#undef OXHIP_CPHASE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (split > 1) {
+        // this part's sums into the problem's accumulator; the last part to arrive writes the state.
+        // H_final = H0 P^N + sum_parts Hpart P^(N - j_hi)
+        uint64_t w = 1, base = kFnvPrime;
+        for (uint32_t e = budget_all - j_hi; e != 0; e >>= 1) { if (e & 1u) w *= base; base *= base; }
+        CellAcc& acc = p.cell_acc[prob];
+        uint32_t arrived = 0;
+        if (lane == 0) {
+            atomicAdd((unsigned long long*)&acc.chk, (unsigned long long)(st.checksum * w));
+            atomicAdd((unsigned long long*)&acc.accepted, (unsigned long long)st.accepted);
+            if (part == split - 1u) atomicExch((unsigned long long*)&acc.pos, (unsigned long long)draws_done);
+            __threadfence();
+            arrived = atomicAdd(&acc.done, 1u);
+        }
+        arrived = uni(arrived);
+        if (arrived == split - 1u && lane == 0) {
+            __threadfence();
+            uint64_t pn = 1, b2 = kFnvPrime;
+            for (uint32_t e = budget_all; e != 0; e >>= 1) { if (e & 1u) pn *= b2; b2 *= b2; }
+            ProblemState out = st0;
+            out.checksum = st0.checksum * pn + (uint64_t)atomicAdd((unsigned long long*)&acc.chk, 0ull);
+            out.accepted = st0.accepted + (uint64_t)atomicAdd((unsigned long long*)&acc.accepted, 0ull);
+            out.iterations = st0.iterations + budget_all;
+            out.draws = (uint64_t)atomicAdd((unsigned long long*)&acc.pos, 0ull);
+            out.stop_reason = 1;
+            p.state[prob] = out;
+            acc.chk = 0; acc.accepted = 0; acc.pos = 0; acc.done = 0;
+        }
+    } else if (lane == 0) {
+        st.n_nodes = n;
+        st.draws = draws_done;
+        st.stop_reason = stop;
+        p.state[prob] = st;
+    }
+    if (!p.freeze) grid_store<DIM>(meta, grid, n, mabs_bits, lane);
+    if (STAMP && p.dbg && lane == 0) {
+        atomicAdd((unsigned long long*)&p.dbg[54], (unsigned long long)n_amb);
+        atomicAdd((unsigned long long*)&p.dbg[55], (unsigned long long)n_memo);
+        atomicAdd((unsigned long long*)&p.dbg[56], (unsigned long long)n_cut_conflict);
+        atomicAdd((unsigned long long*)&p.dbg[59], (unsigned long long)n_forced);
+        atomicAdd((unsigned long long*)&p.dbg[60], (unsigned long long)n_expand);
+        atomicAdd((unsigned long long*)&p.dbg[61], (unsigned long long)n_regrid);
+        atomicAdd((unsigned long long*)&p.dbg[45], (unsigned long long)n_amb);
+        if (prob == 0 && part == 0) {
+            p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict;
+            p.dbg[15] = n_tie; p.dbg[11] = n_memo; p.dbg[8] = n_expand; p.dbg[9] = n_steps; p.dbg[10] = n_regrid;
+            for (int i = 0; i < 8; ++i) p.dbg[32 + i] = t_ph[i];
+            p.dbg[13] = (uint64_t)clock64() - t_begin;
+        }
+    }
+}
+
+// Before every launch of rrt_cells_kernel, one wave per problem: (re)build the grid when it does not cover the tree as it
+// is (first launch, after setup / set_tree), and -- for a split frozen launch -- run the sampler's position arithmetic over
+// the whole budget to learn the stream position at which each part starts (rrt.rs:177-184: a goal sample takes one word,
+// a uniform sample 1 + D; nothing else of the draws is evaluated).
+template <int DIM>
+__global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
+    __shared__ CellsWaveLds<DIM> shw;
+    const uint32_t prob = blockIdx.x, lane = threadIdx.x;
+    const ProblemState st0 = p.state[prob];
+    if (p.stop_at_goal && st0.goal_node >= 0) return;
+    CellMeta& meta = p.cell_meta[prob];
+    const uint32_t n = st0.n_nodes;
+    double c0[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) c0[k] = 0.5 * p.lo[k] + 0.5 * p.hi[k];
+    const bool valid = uni(meta.valid) != 0 && uni(meta.n_grid) == n &&
+                       (p.freeze || n < uni(meta.regrid_at)) && uni(meta.level) == cells_level(n, DIM, p.cell_level_max);
+    if (!valid) {
+        CellGrid g;
+        uint32_t mabs_bits;
+        cells_build<DIM>(p, prob, n, lane, c0, g, mabs_bits);
+        grid_store<DIM>(meta, g, n, mabs_bits, lane);
+    }
+    const uint32_t split = p.freeze ? p.cells_split : 1u;
+    if (split <= 1) return;
+    double goal_c[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
+    RngWindow rng;
+    rng.init(shw.rng_buf, p.seed, p.first_problem_id + prob, st0.draws);
+    const uint32_t budget = (uint32_t)p.budget, rounds = (budget + 63u) / 64u;
+    uint32_t next_part = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        while (next_part < split && (uint32_t)(((uint64_t)rounds * next_part) / split) == r) {
+            if (lane == 0) p.cell_part_pos[(size_t)prob * 8u + next_part] = rng.pos;
+            ++next_part;
+        }
+        if (next_part >= split) break;
+        const uint32_t m = budget - r * 64u < 64u ? budget - r * 64u : 64u;
+        cells_sample_block<DIM, false>(rng, p, goal_c, m, lane, &shw, r * 64u);
+    }
+    while (next_part < split) {   // (parts without a round start where the stream ends)
+        if (lane == 0) p.cell_part_pos[(size_t)prob * 8u + next_part] = rng.pos;
+        ++next_part;
+    }
+}
+
+bool cells_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && cap <= (1u << 20); }
+
+// grid level a tree of `cap` nodes can reach: the heads array is sized for it
+uint32_t cells_level_max(uint32_t dim, uint32_t cap) {
+    uint32_t l = 0;
+    while ((1ull << (dim * (l + 1))) <= (unsigned long long)cap) ++l;
+    const uint32_t lim = dim == 2 ? 7u : 5u;   // at most 128^2 / 32^3 cells: binary32 cell coordinates keep 2^-16 cells or better
+    return l < lim ? l : lim;
+}
+
+template <int DIM>
+static void launch_cells_dim(const DevParams& p, hipStream_t stream) {
+    hipLaunchKernelGGL((cells_prepare_kernel<DIM>), dim3(p.n_problems), dim3(64), 0, stream, p);
+    const uint32_t split = p.freeze ? p.cells_split : 1u;
+    const uint32_t per_xcd = (p.n_problems + 7u) / 8u;
+    const uint32_t wgs_per_xcd = (per_xcd * split + (uint32_t)kCellsWaves - 1u) / (uint32_t)kCellsWaves;
+    dim3 grid(8u * wgs_per_xcd), block(kCellsWaves * 64);
+    if (p.dbg) hipLaunchKernelGGL((rrt_cells_kernel<DIM, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((rrt_cells_kernel<DIM, false>), grid, block, 0, stream, p);
+}
+
+void launch_rrt_cells(const DevParams& p, hipStream_t stream) {
+    if (p.dim == 2) launch_cells_dim<2>(p, stream);
+    else if (p.dim == 3) launch_cells_dim<3>(p, stream);
+}
+
+}  // namespace oxhip

@@ -53,6 +53,24 @@ struct StarChunk {
     uint32_t j[32];              // ascending neighbour indices
 };
 
+// rrt_cells.hip: a problem's cell grid (HBM, persists between launches) and the accumulator of a split frozen launch
+struct CellMeta {
+    double lo[3];          // grid origin: the corner of the box around the bounds, the goal centre and the tree
+    double inv_h;          // 1 / cell size (cubic cells)
+    uint32_t G[3];         // cells per axis
+    uint32_t level;        // G = 2^level along the longest side (0: no grid, every node by index)
+    uint32_t n_grid;       // tree nodes the grid covers
+    uint32_t regrid_at;    // tree size at which the next finer grid takes over
+    uint32_t valid;        // 0 after setup / set_tree
+    float delta_node;      // bound on |stored - true| of any node coordinate, cell units
+    uint32_t mabs_bits;    // bits of the largest |fl32(coordinate - c0)| over the tree
+    uint32_t pad;
+};
+struct CellAcc {
+    uint64_t chk, accepted, pos;
+    uint32_t done, pad;
+};
+
 // kernel arguments (by value)
 struct DevParams {
     uint32_t dim, n_problems, cap, max_nodes;
@@ -111,6 +129,13 @@ struct DevParams {
     uint32_t dbg_flags;     // oxhip_rrt_config.debug_flags (oxhip_debug_flag bits): test-only switches, results identical
     uint32_t goal_sampler;  // oxhip_goal_sampler
     const double* goal_r;   // [P] goal radii as given (the disc sampler scales by them)
+    // rrt_cells.hip
+    float* cell_node;        // [P][cap][4]: node i as (tx, ty, tz, next): position in cell units, next node of its cell's list
+    uint32_t* cell_head;     // [P][cell_heads]: first node of every cell's list (0xFFFFFFFF: empty)
+    CellMeta* cell_meta;     // [P]
+    CellAcc* cell_acc;       // [P] zero between launches
+    uint64_t* cell_part_pos; // [P][8] stream position at which each part of a split frozen launch starts
+    uint32_t cell_heads, cell_level_max, cells_split;
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }

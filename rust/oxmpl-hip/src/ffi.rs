@@ -60,6 +60,8 @@ pub struct OxhipRrtConfig {
     pub goal_sampler: u32,
     pub debug_flags: u32,
     pub star_pool_share: u32,
+    pub frozen_split: u32,
+    pub reserved: u32,
 }
 
 /// (field, byte offset, byte size) of `oxhip_rrt_config`
@@ -83,8 +85,10 @@ pub const OXHIP_RRT_CONFIG_LAYOUT: &[(&str, usize, usize)] = &[
     ("goal_sampler", 212, 4),
     ("debug_flags", 216, 4),
     ("star_pool_share", 220, 4),
+    ("frozen_split", 224, 4),
+    ("reserved", 228, 4),
 ];
-pub const OXHIP_RRT_CONFIG_SIZE: usize = 224;
+pub const OXHIP_RRT_CONFIG_SIZE: usize = 232;
 
 /// `oxhip_prm_config` (include/oxmpl_hip.h): PRM::new(timeout, connection_radius) (prm.rs:70-78) + the space.
 #[repr(C)]
@@ -223,7 +227,7 @@ mod tests {
     fn repr_c_structs_match_the_layout_tables() {
         check_layout!(OxhipRrtConfig, OXHIP_RRT_CONFIG_LAYOUT, OXHIP_RRT_CONFIG_SIZE,
             [struct_size, dim, bounds, max_distance, goal_bias, lvs_fraction, n_problems, max_nodes, stop_at_goal, kernel,
-             seed, first_problem_id, device, planner, search_radius, space, goal_sampler, debug_flags, star_pool_share]);
+             seed, first_problem_id, device, planner, search_radius, space, goal_sampler, debug_flags, star_pool_share, frozen_split, reserved]);
         check_layout!(OxhipPrmConfig, OXHIP_PRM_CONFIG_LAYOUT, OXHIP_PRM_CONFIG_SIZE,
             [struct_size, dim, bounds, timeout, connection_radius, lvs_fraction, max_milestones, device, max_samples, seed, stream]);
     }

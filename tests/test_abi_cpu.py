@@ -26,7 +26,7 @@ def test_header_and_binding_export_the_same_symbols(L):
     for name in declared:
         assert hasattr(L, name), name
     assert L.oxhip_abi_version() == capi.ABI_VERSION == 2
-    assert C.sizeof(capi.Config) == 224  # layout of oxhip_rrt_config on the ABI
+    assert C.sizeof(capi.Config) == 232  # layout of oxhip_rrt_config on the ABI
     assert C.sizeof(capi.PrmConfig) == 192  # oxhip_prm_config
 
 

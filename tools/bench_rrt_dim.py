@@ -39,7 +39,7 @@ for _ in range(3):
     ms += g.last_timing()["kernel_ms"]
 ms /= 3
 its = P * iters / (ms * 1e-3)
-print(json.dumps({"planner": "RRT", "dim": dim, "problems": P, "nodes": nodes, "kernel": {1: "stream", 2: "resident", 5: "lanes"}[g.last_timing()["kernel"]],
+print(json.dumps({"planner": "RRT", "dim": dim, "problems": P, "nodes": nodes, "kernel": {1: "stream", 2: "resident", 5: "lanes", 6: "cells"}[g.last_timing()["kernel"]],
                   "grow_iterations_per_s": grow_its / (grow_ms * 1e-3), "grow_kernel_ms": grow_ms,
                   "steady_iterations_per_s": its, "steady_kernel_ms": ms,
                   "roofline": {"bound": "hbm", "achieved": its * nodes * dim * 8 / 1e9, "peak": 8000.0, "unit": "GB/s",

@@ -80,7 +80,7 @@ def leg_b(P, nodes=10000):
     its = int(c["iterations"].sum())
     g.close()
     return dict(problems=P, nodes=nodes, iterations=its, gpu_create_setup_ms=(t1 - t0) * 1e3, gpu_solve_wall_ms=(t2 - t1) * 1e3,
-                gpu_kernel_ms=tm["kernel_ms"], launches=tm["launches"], kernel={1: "stream", 2: "resident", 5: "lanes"}[tm["kernel"]],
+                gpu_kernel_ms=tm["kernel_ms"], launches=tm["launches"], kernel={1: "stream", 2: "resident", 5: "lanes", 6: "cells"}[tm["kernel"]],
                 gpu_iterations_per_s=its / (t2 - t1), cpu_1core_one_problem_ms=(t4 - t3) * 1e3,
                 cpu_1core_iterations_per_s=o.iterations / (t4 - t3),
                 gpu_over_one_core=(its / (t2 - t1)) / (o.iterations / (t4 - t3)))
