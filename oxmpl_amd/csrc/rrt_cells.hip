@@ -510,19 +510,49 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
             verdict = cells_verdict(t2, __builtin_inf(), A);
         } else {
             constexpr int NR = DIM == 3 ? 9 : 3;   // rows of the 3^D block: the cells of a row are the x-neighbours
+            // (1) the query's own cell
+            {
+                uint32_t cur = act ? __hip_atomic_load(&heads[(cq[2] * grid.G[1] + cq[1]) * grid.G[0] + cq[0]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : kCellEnd;
+                while (__ballot(cur != kCellEnd) != 0) {
+                    if (STAMP) ++n_steps;
+                    const bool on = cur != kCellEnd;
+                    const cfloat4 nd = nodes[on ? cur : 0u];
+                    top2_push(t2, on ? cell_s<DIM>(nd, tq) : __builtin_inff(), cur);
+                    cur = on ? lf32_bits(nd[3]) : kCellEnd;
+                }
+            }
+            // (2) of the other 3^D - 1 cells only those whose box comes within (d1 + 2A) of the query: every node of a skipped
+            //     cell is farther than that, so it can neither beat nor tie with the final winner (whose d1 can only shrink)
+            float thr2;
+            {
+                const double dd = sqrt((double)t2.s1) * (1.0 + 0x1p-20) + 2.0 * A;
+                thr2 = t2.s1 < __builtin_inff() ? f32_up(dd * dd * (1.0 + 0x1p-20)) : __builtin_inff();
+            }
+            float gap_lo[3], gap_hi[3];   // distance (cell units) from the query to its cell's low / high face along each axis
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                gap_lo[k] = fmaxf(tq[k] - (float)cq[k], 0.0f) * (1.0f - 0x1p-20f);
+                gap_hi[k] = fmaxf((float)(cq[k] + 1u) - tq[k], 0.0f) * (1.0f - 0x1p-20f);
+            }
             uint32_t hd[NR][3];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const int dy = r % 3 - 1, dz = r / 3 - 1;
-                const int cy = (int)cq[1] + dy, cz = (int)cq[2] + (DIM == 3 ? dz : 0);
+                const int dy = r % 3 - 1, dz = DIM == 3 ? r / 3 - 1 : 0;
+                const int cy = (int)cq[1] + dy, cz = (int)cq[2] + dz;
                 const bool row_ok = act && cy >= 0 && cy < (int)grid.G[1] && cz >= 0 && cz < (int)grid.G[2];
                 const uint32_t base = ((uint32_t)(row_ok ? cz : 0) * grid.G[1] + (uint32_t)(row_ok ? cy : 0)) * grid.G[0];
+                const float gy = dy < 0 ? gap_lo[1] : (dy > 0 ? gap_hi[1] : 0.0f), gz = dz < 0 ? gap_lo[2] : (dz > 0 ? gap_hi[2] : 0.0f);
+                const float lb_yz = __builtin_fmaf(gy, gy, gz * gz);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int cx = (int)cq[0] + c - 1;
-                    const bool ok = row_ok && cx >= 0 && cx < (int)grid.G[0];
-                    const uint32_t v = __hip_atomic_load(&heads[base + (uint32_t)(ok ? cx : 0)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hd[r][c] = ok ? v : kCellEnd;
+                    const float gx = c == 0 ? gap_lo[0] : (c == 2 ? gap_hi[0] : 0.0f);
+                    const bool own = c == 1 && dy == 0 && dz == 0;
+                    const bool ok = row_ok && !own && cx >= 0 && cx < (int)grid.G[0] && !(__builtin_fmaf(gx, gx, lb_yz) > thr2);
+                    uint32_t v = kCellEnd;
+                    if (ok) v = __hip_atomic_load(&heads[base + (uint32_t)cx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hd[r][c] = v;
                 }
             }
 #pragma unroll
@@ -538,7 +568,10 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
                     if (STAMP) ++n_steps;
                     cfloat4 nd[NR];
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) nd[r] = nodes[cur[r] != kCellEnd ? cur[r] : 0u];
+                    for (int r = 0; r < NR; ++r) {
+                        nd[r] = cfloat4{0.0f, 0.0f, 0.0f, 0.0f};
+                        if (cur[r] != kCellEnd) nd[r] = nodes[cur[r]];
+                    }
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const bool on = cur[r] != kCellEnd;
