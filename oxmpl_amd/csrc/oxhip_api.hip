@@ -30,8 +30,8 @@ struct oxhip_rrt_batch {
     DevBuf<double> tree, goal_c, goal_thr, goal_r, sph_c, sph_thr, sph_filt, box_lo, box_hi;
     std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
     bool filt_dirty = true;
-    DevBuf<float> cell_node;        // rrt_cells.hip: per-cell node lists, grid descriptors, accumulators of split frozen launches
-    DevBuf<uint32_t> cell_head;
+    DevBuf<CellBlock> cell_blk;     // rrt_cells.hip: cell blocks, flat lists of small trees, grid descriptors, accumulators of split frozen launches
+    DevBuf<float> cell_flat;
     DevBuf<CellMeta> cell_meta;
     DevBuf<CellAcc> cell_acc;
     DevBuf<uint64_t> cell_part_pos;
@@ -268,18 +268,18 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (kind == OXHIP_KERNEL_CELLS) {
         if (!cells_supported(dim, cap)) {
             oxhip_rrt_batch_destroy(b);
-            return fail(OXHIP_ERR_BAD_ARG, "cell-grid kernel: R^2 / R^3 trees of at most 2^20 nodes");
+            return fail(OXHIP_ERR_BAD_ARG, "cell-grid kernel: R^2 / R^3 trees of at most 64,512 nodes");
         }
         dp.cell_level_max = cells_level_max(dim, cap);
-        dp.cell_heads = 1u << (dim * dp.cell_level_max);
-        if (dp.cell_heads < 64u) dp.cell_heads = 64u;
+        // head blocks for the finest grid this capacity reaches + the overflow blocks (n nodes overflow into at most n / 7)
+        dp.cell_blocks = cells_head_blocks(dim, cap) + cap / 7u + 64u;
         // frozen launches: a problem's iterations are independent, so they are divided over enough waves to fill the chip
         // (256 CUs x 8 waves of this kernel's register budget)
         uint32_t split = cfg->frozen_split;
         if (split == 0) { split = (2048u + P - 1u) / P; if (split > 8u) split = 8u; if (split < 1u) split = 1u; }
         dp.cells_split = split;
-        hipError_t e2 = b->cell_node.alloc((size_t)P * cap * 4);
-        if (e2 == hipSuccess) e2 = b->cell_head.alloc((size_t)P * dp.cell_heads);
+        hipError_t e2 = b->cell_blk.alloc((size_t)P * dp.cell_blocks);
+        if (e2 == hipSuccess) e2 = b->cell_flat.alloc((size_t)P * 1024 * 4);
         if (e2 == hipSuccess) e2 = b->cell_meta.alloc(P);
         if (e2 == hipSuccess) e2 = b->cell_acc.alloc(P);
         if (e2 == hipSuccess) e2 = b->cell_part_pos.alloc((size_t)P * 8);
@@ -290,7 +290,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             oxhip_rrt_batch_destroy(b);
             return fail(OXHIP_ERR_HIP, msg);
         }
-        dp.cell_node = b->cell_node.p; dp.cell_head = b->cell_head.p; dp.cell_meta = b->cell_meta.p;
+        dp.cell_blk = b->cell_blk.p; dp.cell_flat = b->cell_flat.p; dp.cell_meta = b->cell_meta.p;
         dp.cell_acc = b->cell_acc.p; dp.cell_part_pos = b->cell_part_pos.p;
     }
     if (kind == OXHIP_KERNEL_LANES && !lanes_supported(dim, cap)) {

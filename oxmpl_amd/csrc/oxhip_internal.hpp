@@ -58,6 +58,7 @@ void launch_rrt_lanes(const DevParams& p, hipStream_t stream);
 // rrt_cells.hip: one wave per problem, nearest neighbour through an exact cell grid (R^2, R^3)
 bool cells_supported(uint32_t dim, uint32_t cap);
 uint32_t cells_level_max(uint32_t dim, uint32_t cap);
+uint32_t cells_head_blocks(uint32_t dim, uint32_t cap);
 void launch_rrt_cells(const DevParams& p, hipStream_t stream);
 
 // prm_kernels.hip: PRM roadmap construction / query (prm.rs)

@@ -8,9 +8,10 @@
 //   other waves, no workgroup barrier after the launch's first.
 // * nearest neighbour: the nodes live in a uniform grid of cubic cells over the bounding box of the bounds, the goal centre
 //   and the tree -- G = 2^floor(log2(n) / D) cells along the longest side, ~1 to 2^D nodes per cell, re-gridded whenever n
-//   reaches the next power -- as per-cell linked lists in HBM / L2: heads[cell] and node i = (tx, ty, tz, next), its position
-//   in CELL UNITS as binary32.  A lane walks the 3^D cells around its query's cell (9 chains at a time, their loads in
-//   flight together), keeps the smallest and the second smallest binary32 squared distance, and accepts the smallest iff
+//   reaches the next power -- as one 64-byte BLOCK per cell in HBM / L2: a counter and seven entries (x, y, z, node), the
+//   position inside the cell in 2^-16 cell units (a fuller cell chains further blocks).  A lane reads its query's own cell,
+//   then -- four blocks in flight at a time -- only those of the other 3^D - 1 cells whose box comes within d1 + 2A of the
+//   query, keeps the smallest and the second smallest binary32 squared distance, and accepts the smallest iff
 //     d1 + A < d2 - A        (no other visited node can be nearer or tie:  A = sqrt(D) delta, delta the bound on any stored
 //                             coordinate's and the query's error in cell units: Gmax 2^-23 + the measured clamping error)
 //     d1 + A < lb            (no unvisited node can: lb = distance from the query to the nearest open face of the block)
@@ -18,8 +19,8 @@
 //   every other kernel.  When lb fails (a query deep inside an obstacle, a sparse tree) the WAVE searches the next shells of
 //   cells for that one query; when the margin fails (1e-4 of queries) the query takes the whole-tree path: the reference's
 //   d2 scan / literal loop over the binary64 tree.  Trees of up to 1,024 nodes are scanned node by node (uniform addresses).
-// * inserting a node is one atomic exchange on its cell's head: the grid is always current, there is no "nodes committed
-//   since the snapshot" to fold in, no rebuild, no sorted order to maintain.
+// * inserting a node is one atomic increment of its cell's counter and an 8-byte store: the grid is always current, there is
+//   no "nodes committed since the snapshot" to fold in, no rebuild, no sorted order to maintain.
 // * with inserts suppressed (the steady measurement) the queries of a launch are independent: a problem's launch is cut into
 //   `split` contiguous parts, one wave each (stream positions of the part starts from cells_prepare_kernel), whose checksum
 //   polynomials and counters are summed with atomics; the last part to finish writes the problem's state.
@@ -33,21 +34,25 @@
 
 namespace oxhip {
 
-constexpr uint32_t kCellEnd = 0xFFFFFFFFu;
 #ifndef OXHIP_CELLS_BRUTE
 #define OXHIP_CELLS_BRUTE 1024
 #endif
 constexpr uint32_t kBruteMax = OXHIP_CELLS_BRUTE;   // trees up to this size: every node, by index
 constexpr int kCellsWaves = 4;                       // waves (= problems, or parts of problems) per workgroup
 constexpr int kMaxShell = 6;                         // the cooperative search gives up beyond this ring (-> whole-tree path)
+#ifndef OXHIP_CELLS_NB
+#define OXHIP_CELLS_NB 4                             // neighbour cells in flight per trip
+#endif
 
 typedef float cfloat4 __attribute__((ext_vector_type(4)));
+typedef uint32_t cuint4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kBlkEntries = 7;
 
 struct CellGrid {   // wave-uniform
     double lo[3], inv_h;
     uint32_t G[3];
     uint32_t level, regrid_at;
-    float top[3];        // largest binary32 below G[k]: stored coordinates are clamped to [0, top]
+    uint32_t pool_next;  // next free overflow block
     double delta_node;   // bound on |stored - true| of any node coordinate, cell units
 };
 
@@ -67,10 +72,24 @@ struct CellsShared {
     CellsWaveLds<DIM> w[kCellsWaves];
 };
 
+// Grid level for a tree of n nodes: level l has G_l ~ 2^(l/2) cells along the longest side (steps of sqrt 2, so a regrid
+// thins the cells by 2^(D/2), not 2^D) and serves trees of up to 3.5 G_l^D nodes -- at most 3.5 nodes per cell on average (a
+// block holds seven: the Poisson tail beyond is 3 %), ~1.2 right after a regrid (sparser cells fail the lb test too often).
+__host__ __device__ __forceinline__ uint32_t cells_G(uint32_t level) {
+    const uint32_t t[15] = {1u, 2u, 2u, 3u, 4u, 6u, 8u, 11u, 16u, 23u, 32u, 45u, 64u, 91u, 128u};
+    return t[level < 14u ? level : 14u];
+}
+__host__ __device__ __forceinline__ uint32_t cells_level_cap(uint32_t level, int dim) {   // largest tree level `level` serves
+    unsigned long long v = 7ull;
+    for (int k = 0; k < dim; ++k) v *= cells_G(level);
+    v >>= 1;
+    return v > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)v;
+}
 __device__ __forceinline__ uint32_t cells_level(uint32_t n, int dim, uint32_t level_max) {
     if (n <= kBruteMax) return 0u;
-    const uint32_t l = (31u - (uint32_t)__clz((int)n)) / (uint32_t)dim;
-    return l < level_max ? l : level_max;
+    uint32_t l = 1;
+    while (l < level_max && cells_level_cap(l, dim) < n) ++l;
+    return l;
 }
 
 template <int DIM>
@@ -79,45 +98,81 @@ __device__ __forceinline__ void grid_load(const CellMeta& m, CellGrid& g) {
     for (int k = 0; k < 3; ++k) {
         g.lo[k] = unid(m.lo[k]);
         g.G[k] = uni(m.G[k]);
-        g.top[k] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)g.G[k]) - 1u);
     }
     g.inv_h = unid(m.inv_h);
     g.level = uni(m.level);
     g.regrid_at = uni(m.regrid_at);
+    g.pool_next = uni(m.pool_next);
     g.delta_node = (double)__builtin_bit_cast(float, uni(__builtin_bit_cast(uint32_t, m.delta_node)));
 }
 
-// position of x in cell units as the grid stores it (binary32, clamped into the grid), its cell, and the error made
+// Where node x goes: its cell, its block entry (position inside the cell in 2^-16 cell units, decoded at the bin centre),
+// its position in cell units as binary32 (the flat list of small trees), and the error either representation makes.
 template <int DIM>
-__device__ __forceinline__ uint32_t cell_place(const CellGrid& g, const double x[DIM], float tf[3], double& err) {
-    uint32_t c[3] = {0u, 0u, 0u};
+__device__ __forceinline__ uint32_t cell_place(const CellGrid& g, const double x[DIM], uint32_t idx, uint64_t& entry, float tf[3], double& err) {
+    uint32_t c[3] = {0u, 0u, 0u}, u[3] = {0u, 0u, 0u};
     err = 0.0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
+        tf[k] = 0.0f;
         if (k < DIM) {
             const double t = (x[k] - g.lo[k]) * g.inv_h;
-            float f = (float)t;
-            f = fminf(fmaxf(f, 0.0f), g.top[k]);   // (NaN -> 0; never expected: nodes are finite)
-            tf[k] = f;
-            err = fmax(err, fabs((double)f - t));
-            c[k] = (uint32_t)f;
-        } else {
-            tf[k] = 0.0f;
+            tf[k] = (float)t;
+            const double fl = floor(t);
+            const uint32_t ci = fl > 0.0 ? (fl < (double)g.G[k] ? (uint32_t)fl : g.G[k] - 1u) : 0u;   // (NaN -> 0; never expected)
+            const double fr = (t - (double)ci) * 65536.0;
+            const uint32_t ui = fr > 0.0 ? (fr < 65535.0 ? (uint32_t)fr : 65535u) : 0u;
+            const double dec = (double)ci + ((double)ui + 0.5) * 0x1p-16;
+            err = fmax(err, g.level == 0 ? fabs((double)tf[k] - t) : fabs(dec - t));
+            c[k] = ci;
+            u[k] = ui;
         }
     }
+    entry = (uint64_t)(u[0] | (u[1] << 16)) | ((uint64_t)(u[2] | (idx << 16)) << 32);
     return (c[2] * g.G[1] + c[1]) * g.G[0] + c[0];
 }
 
+// Append `entry` to cell `cell` for the lanes with `pred`: slot = the cell's counter, atomically (several lanes of a round may
+// share a cell); slots beyond the head block go to chained blocks, one lane at a time (rare: a cell holds ~1 .. 2^D nodes).
+__device__ __forceinline__ void cells_insert(CellBlock* blk, uint32_t& pool_next, uint32_t cell, uint64_t entry, bool pred, uint32_t lane) {
+    uint32_t slot = 0;
+    if (pred) slot = __hip_atomic_fetch_add(&blk[cell].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (pred && slot < kBlkEntries) blk[cell].e[slot] = entry;
+    uint64_t over = __ballot(pred && slot >= kBlkEntries);
+    while (over != 0) {
+        const int j = __ffsll((unsigned long long)over) - 1;
+        over &= over - 1;
+        const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)cell, j), sj = (uint32_t)__builtin_amdgcn_readlane((int)slot, j);
+        const uint64_t ej = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(entry >> 32), j) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)entry, j);
+        uint32_t b = cj;
+        for (uint32_t t = 0; t < sj / kBlkEntries; ++t) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            uint32_t nx = uni(__hip_atomic_load(&blk[b].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (nx == 0) {
+                nx = pool_next++;
+                if (lane == 0) {
+                    blk[nx].count = 0;
+                    blk[nx].next = 0;
+                    __hip_atomic_store(&blk[b].next, nx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            b = nx;
+        }
+        if (lane == 0) blk[b].e[sj % kBlkEntries] = ej;
+    }
+}
+
 // (Re)build the grid of problem `prob` for its n nodes: one wave.  Chooses the level from n, the box from the bounds, the
-// goal centre and the nodes; links every node that is not a skipped duplicate.  Returns the largest |fl32(x - c0)| bits.
+// goal centre and the nodes; files every node that is not a skipped duplicate.
 template <int DIM>
 __device__ __forceinline__ void cells_build(const DevParams& p, uint32_t prob, uint32_t n, uint32_t lane, const double* c0, CellGrid& g,
                                             uint32_t& mabs_bits) {
     const size_t cap = p.cap;
     const double* tree = p.tree + (size_t)prob * DIM * cap;
     const uint8_t* skip = p.skip + (size_t)prob * cap;
-    uint32_t* heads = p.cell_head + (size_t)prob * p.cell_heads;
-    cfloat4* nodes = reinterpret_cast<cfloat4*>(p.cell_node) + (size_t)prob * cap;
+    CellBlock* blk = p.cell_blk + (size_t)prob * p.cell_blocks;
+    cfloat4* flat = reinterpret_cast<cfloat4*>(p.cell_flat) + (size_t)prob * kBruteMax;
     double lo[DIM], hi[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
@@ -145,7 +200,7 @@ __device__ __forceinline__ void cells_build(const DevParams& p, uint32_t prob, u
         wmax = fmax(wmax, hi[k] - lo[k]);
     }
     g.level = cells_level(n, DIM, p.cell_level_max);
-    const uint32_t G = 1u << g.level;
+    const uint32_t G = cells_G(g.level);
     g.inv_h = (double)G / wmax;   // (wmax > 0: create() refuses lo >= hi)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -157,31 +212,31 @@ __device__ __forceinline__ void cells_build(const DevParams& p, uint32_t prob, u
             g.lo[k] = 0.0;
             g.G[k] = 1u;
         }
-        g.top[k] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, (float)g.G[k]) - 1u);
     }
-    g.regrid_at = n <= kBruteMax ? kBruteMax + 1u
-                                 : (g.level < p.cell_level_max ? (1u << ((uint32_t)DIM * (g.level + 1u))) : 0xFFFFFFFFu);
+    g.regrid_at = n <= kBruteMax ? kBruteMax + 1u : (g.level < p.cell_level_max ? cells_level_cap(g.level, DIM) + 1u : 0xFFFFFFFFu);
     const uint32_t nc = g.G[0] * g.G[1] * g.G[2];
-    for (uint32_t c = lane; c < nc; c += 64) heads[c] = kCellEnd;
+    if (g.level != 0)
+        for (uint32_t c = lane; c < nc; c += 64) { blk[c].count = 0; blk[c].next = 0; }
+    g.pool_next = nc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     double derr = 0.0;
-    for (uint32_t i = lane; i < n; i += 64) {
+    for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        const bool in = i < n;
         double x[DIM];
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) x[k] = tree[(size_t)k * cap + i];
+        for (int k = 0; k < DIM; ++k) x[k] = tree[(size_t)k * cap + (in ? i : 0u)];
         float tf[3];
         double err;
-        const uint32_t cell = cell_place<DIM>(g, x, tf, err);
-        cfloat4 nd;
-        if (skip[i] == 0) {
-            derr = fmax(derr, err);
-            const uint32_t old = g.level == 0 ? kCellEnd
-                                              : __hip_atomic_exchange(&heads[cell], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            nd = cfloat4{tf[0], tf[1], tf[2], lbits_f32(old)};
-        } else {   // a duplicate of a lower-index node can never win (strict '<', rrt.rs:192): not in the grid
-            nd = cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), lbits_f32(kCellEnd)};
+        uint64_t entry;
+        const uint32_t cell = cell_place<DIM>(g, x, i, entry, tf, err);
+        const bool keep = in && skip[in ? i : 0u] == 0;   // a duplicate of a lower-index node can never win (strict '<', rrt.rs:192)
+        if (keep) derr = fmax(derr, err);
+        if (g.level == 0) {
+            if (in) flat[i] = keep ? cfloat4{tf[0], tf[1], tf[2], 0.0f} : cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f};
+        } else {
+            cells_insert(blk, g.pool_next, cell, entry, keep, lane);
         }
-        nodes[i] = nd;
     }
     derr = -wave_min_f64(-derr);
     g.delta_node = (double)f32_up(derr * (1.0 + 1e-9) + 1e-30);
@@ -196,6 +251,7 @@ __device__ __forceinline__ void grid_store(CellMeta& m, const CellGrid& g, uint3
         m.inv_h = g.inv_h;
         m.level = g.level;
         m.regrid_at = g.regrid_at;
+        m.pool_next = g.pool_next;
         m.n_grid = n;
         m.delta_node = (float)g.delta_node;   // (exact: it came from a float)
         m.mabs_bits = mabs_bits;
@@ -306,6 +362,58 @@ __device__ __forceinline__ float cell_s(const cfloat4& nd, const float (&tq)[3])
     return s;
 }
 
+// one block (16 dwords: count, next, seven entries) against a query: the entries e < nvalid are pushed.  off = (cell + half a
+// bin) - query, so that a coordinate decodes with one fused multiply-add.
+template <int DIM>
+__device__ __forceinline__ void block_eval(const cuint4 (&v)[4], uint32_t nvalid, const float (&off)[3], Top2& t2) {
+#pragma unroll
+    for (int e = 0; e < (int)kBlkEntries; ++e) {
+        if (__ballot((uint32_t)e < nvalid) == 0) break;   // (uniform)
+        const uint32_t lo = v[(2 + 2 * e) / 4][(2 + 2 * e) % 4], hi = v[(3 + 2 * e) / 4][(3 + 2 * e) % 4];
+        const float ex = __builtin_fmaf((float)(lo & 0xFFFFu), 0x1p-16f, off[0]);
+        const float ey = __builtin_fmaf((float)(lo >> 16), 0x1p-16f, off[1]);
+        float s = ex * ex;
+        s = __builtin_fmaf(ey, ey, s);
+        if (DIM >= 3) {
+            const float ez = __builtin_fmaf((float)(hi & 0xFFFFu), 0x1p-16f, off[2]);
+            s = __builtin_fmaf(ez, ez, s);
+        }
+        top2_push(t2, (uint32_t)e < nvalid ? s : __builtin_inff(), hi >> 16);
+    }
+}
+__device__ __forceinline__ void block_load(const CellBlock* blk, uint32_t b, cuint4 (&v)[4]) {
+    const cuint4* src = reinterpret_cast<const cuint4*>(blk + b);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[t] = src[t];
+}
+// the chained blocks of a cell that holds more than seven nodes (entries 7 .. cnt - 1)
+template <int DIM>
+__device__ __forceinline__ void chain_follow(const CellBlock* blk, uint32_t next, uint32_t cnt, bool on, const float (&off)[3], Top2& t2) {
+    uint32_t base = kBlkEntries;
+    bool go = on && cnt > kBlkEntries && next != 0;
+    while (__ballot(go) != 0) {
+        cuint4 v[4];
+        block_load(blk, go ? next : 0u, v);
+        const uint32_t left = go ? cnt - base : 0u;
+        block_eval<DIM>(v, left < kBlkEntries ? left : kBlkEntries, off, t2);
+        base += kBlkEntries;
+        next = v[0][1];
+        go = go && base < cnt && next != 0;
+    }
+}
+// a whole cell for the lanes with `on`
+template <int DIM>
+__device__ __forceinline__ void cell_visit(const CellBlock* blk, uint32_t cell, bool on, const uint32_t (&cc)[3], const float (&tq)[3], Top2& t2) {
+    float off[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) off[k] = ((float)cc[k] + 0x1p-17f) - tq[k];
+    cuint4 v[4];
+    block_load(blk, on ? cell : 0u, v);
+    const uint32_t cnt = on ? v[0][0] : 0u;
+    block_eval<DIM>(v, cnt < kBlkEntries ? cnt : kBlkEntries, off, t2);
+    if (__ballot(cnt > kBlkEntries) != 0) chain_follow<DIM>(blk, v[0][1], cnt, on, off, t2);
+}
+
 // distance (cell units) from tq to the nearest OPEN face of the block of cells [cq - r, cq + r] (+inf: the block is the grid)
 template <int DIM>
 __device__ __forceinline__ double block_lb(const CellGrid& g, const float (&tq)[3], const uint32_t (&cq)[3], uint32_t r) {
@@ -406,8 +514,8 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
     double* tree = p.tree + (size_t)prob * DIM * cap;
     int32_t* parent = p.parent + (size_t)prob * cap;
     uint8_t* skip = p.skip + (size_t)prob * cap;
-    uint32_t* heads = p.cell_head + (size_t)prob * p.cell_heads;
-    cfloat4* nodes = reinterpret_cast<cfloat4*>(p.cell_node) + (size_t)prob * cap;
+    CellBlock* blk = p.cell_blk + (size_t)prob * p.cell_blocks;
+    cfloat4* flat = reinterpret_cast<cfloat4*>(p.cell_flat) + (size_t)prob * kBruteMax;
     double goal_c[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
@@ -491,37 +599,35 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
             cq[k] = fl > 0.0f ? (fl < (float)grid.G[k] ? (uint32_t)fl : grid.G[k] - 1u) : 0u;   // (NaN -> 0)
         }
         const uint32_t gmax = grid.G[0] > grid.G[1] ? (grid.G[0] > grid.G[2] ? grid.G[0] : grid.G[2]) : (grid.G[1] > grid.G[2] ? grid.G[1] : grid.G[2]);
-        const double A = sqrt((double)D) * (grid.delta_node + (double)gmax * 0x1p-23) * 1.01 + 1e-30;
+        const double A = sqrt((double)D) * (grid.delta_node + (double)(gmax + 8u) * 0x1p-23) * 1.01 + 1e-30;
         int verdict;   // 0 proven, 2 ambiguous (whole-tree path)
         bool from_memo = act && memo_n == n;
 #pragma unroll
         for (int k = 0; k < D; ++k) from_memo = from_memo && __double_as_longlong(q[k]) == __double_as_longlong(memo_q[k]);
         if (grid.level == 0) {
-            // every node, by index: wave-uniform addresses (one cache line serves all lanes)
-            for (uint32_t i0 = 0; i0 < n; i0 += 4) {
-                cfloat4 nd[4];
+            // every node, by index: a coalesced load gives each lane one node of the next 64, then node after node is
+            // broadcast from its lane (v_readlane -> scalar operands): no memory latency per node
+            cfloat4 mine_nd = flat[lane < n ? lane : 0u];
+            for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+                const cfloat4 cur_nd = mine_nd;
+                const uint32_t nx = i0 + 64u + lane;
+                mine_nd = flat[nx < n ? nx : 0u];   // (the next 64 are on their way while these are processed)
+                const uint32_t cnt = n - i0 < 64u ? n - i0 : 64u;
+                for (uint32_t t = 0; t < cnt; ++t) {
+                    cfloat4 nd;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) nd[t] = nodes[uni(i0 + (uint32_t)t < n ? i0 + (uint32_t)t : 0u)];
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (i0 + (uint32_t)t < n) top2_push(t2, cell_s<DIM>(nd[t], tq), i0 + (uint32_t)t);
+                    for (int k = 0; k < 3; ++k) nd[k] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(cur_nd[k]), (int)t));
+                    nd[3] = 0.0f;
+                    top2_push(t2, cell_s<DIM>(nd, tq), i0 + t);
+                }
             }
             if (STAMP) n_steps += n;
             verdict = cells_verdict(t2, __builtin_inf(), A);
+            OXHIP_CPHASE(7);   // (the flat scan of a small tree)
         } else {
-            constexpr int NR = DIM == 3 ? 9 : 3;   // rows of the 3^D block: the cells of a row are the x-neighbours
             // (1) the query's own cell
-            {
-                uint32_t cur = act ? __hip_atomic_load(&heads[(cq[2] * grid.G[1] + cq[1]) * grid.G[0] + cq[0]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : kCellEnd;
-                while (__ballot(cur != kCellEnd) != 0) {
-                    if (STAMP) ++n_steps;
-                    const bool on = cur != kCellEnd;
-                    const cfloat4 nd = nodes[on ? cur : 0u];
-                    top2_push(t2, on ? cell_s<DIM>(nd, tq) : __builtin_inff(), cur);
-                    cur = on ? lf32_bits(nd[3]) : kCellEnd;
-                }
-            }
+            cell_visit<DIM>(blk, (cq[2] * grid.G[1] + cq[1]) * grid.G[0] + cq[0], act, cq, tq, t2);
+            if (STAMP) ++n_steps;
             // (2) of the other 3^D - 1 cells only those whose box comes within (d1 + 2A) of the query: every node of a skipped
             //     cell is farther than that, so it can neither beat nor tie with the final winner (whose d1 can only shrink)
             float thr2;
@@ -535,55 +641,77 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
                 gap_lo[k] = fmaxf(tq[k] - (float)cq[k], 0.0f) * (1.0f - 0x1p-20f);
                 gap_hi[k] = fmaxf((float)(cq[k] + 1u) - tq[k], 0.0f) * (1.0f - 0x1p-20f);
             }
-            uint32_t hd[NR][3];
+            // bit b of `need` = the b-th neighbour in the order faces, edges, corners (kOrder: b -> o = (dz + 1) 9 + (dy + 1) 3 +
+            // (dx + 1)): the cells most likely to hold the nearest node come first, and the bound shrinks trip by trip
+            constexpr int NO = DIM == 3 ? 26 : 8;
+            constexpr uint8_t kOrder3[26] = {12, 14, 10, 16, 4, 22,  9, 11, 15, 17, 3, 5, 21, 23, 1, 7, 19, 25,  0, 2, 6, 8, 18, 20, 24, 26};
+            constexpr uint8_t kOrder2[8] = {12, 14, 10, 16, 9, 11, 15, 17};
+            auto needed = [&](float thr) -> uint32_t {
+                uint32_t mask = 0;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int dy = r % 3 - 1, dz = DIM == 3 ? r / 3 - 1 : 0;
-                const int cy = (int)cq[1] + dy, cz = (int)cq[2] + dz;
-                const bool row_ok = act && cy >= 0 && cy < (int)grid.G[1] && cz >= 0 && cz < (int)grid.G[2];
-                const uint32_t base = ((uint32_t)(row_ok ? cz : 0) * grid.G[1] + (uint32_t)(row_ok ? cy : 0)) * grid.G[0];
-                const float gy = dy < 0 ? gap_lo[1] : (dy > 0 ? gap_hi[1] : 0.0f), gz = dz < 0 ? gap_lo[2] : (dz > 0 ? gap_hi[2] : 0.0f);
-                const float lb_yz = __builtin_fmaf(gy, gy, gz * gz);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int cx = (int)cq[0] + c - 1;
-                    const float gx = c == 0 ? gap_lo[0] : (c == 2 ? gap_hi[0] : 0.0f);
-                    const bool own = c == 1 && dy == 0 && dz == 0;
-                    const bool ok = row_ok && !own && cx >= 0 && cx < (int)grid.G[0] && !(__builtin_fmaf(gx, gx, lb_yz) > thr2);
-                    uint32_t v = kCellEnd;
-                    if (ok) v = __hip_atomic_load(&heads[base + (uint32_t)cx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    hd[r][c] = v;
+                for (int b = 0; b < NO; ++b) {
+                    const int o = DIM == 3 ? kOrder3[b] : kOrder2[b];
+                    const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
+                    const int cx = (int)cq[0] + dx, cy = (int)cq[1] + dy, cz = (int)cq[2] + dz;
+                    const float gx = dx < 0 ? gap_lo[0] : (dx > 0 ? gap_hi[0] : 0.0f), gy = dy < 0 ? gap_lo[1] : (dy > 0 ? gap_hi[1] : 0.0f);
+                    const float gz = dz < 0 ? gap_lo[2] : (dz > 0 ? gap_hi[2] : 0.0f);
+                    const bool ok = act && cx >= 0 && cx < (int)grid.G[0] && cy >= 0 && cy < (int)grid.G[1] && cz >= 0 && cz < (int)grid.G[2] &&
+                                    !(__builtin_fmaf(gx, gx, __builtin_fmaf(gy, gy, gz * gz)) > thr);
+                    mask |= ok ? (1u << b) : 0u;
                 }
-            }
+                return mask;
+            };
+            uint32_t need = needed(thr2);
+            // a lane's next needed cells, NB cells in flight per trip
+            while (__ballot(need != 0) != 0) {
+                if (STAMP) ++n_steps;
+                constexpr int NB = OXHIP_CELLS_NB;
+                bool on[NB];
+                uint32_t cc[NB][3], cnt[NB];
+                cuint4 v[NB][4];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                uint32_t cur[NR];
-#pragma unroll
-                for (int r = 0; r < NR; ++r) cur[r] = hd[r][c];
-                for (;;) {
-                    bool any = false;
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) any = any || cur[r] != kCellEnd;
-                    if (__ballot(any) == 0) break;
-                    if (STAMP) ++n_steps;
-                    cfloat4 nd[NR];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        nd[r] = cfloat4{0.0f, 0.0f, 0.0f, 0.0f};
-                        if (cur[r] != kCellEnd) nd[r] = nodes[cur[r]];
+                for (int t = 0; t < NB; ++t) {
+                    on[t] = need != 0;
+                    const uint32_t b = on[t] ? (uint32_t)(__ffs((int)need) - 1) : 0u;
+                    need &= need - 1u;
+                    // b -> o through a 5-bit-per-entry table in two 64-bit words and change (registers, no memory)
+                    uint32_t o;
+                    if (DIM == 3) {
+                        constexpr uint64_t w0 = 12ull | 14ull << 5 | 10ull << 10 | 16ull << 15 | 4ull << 20 | 22ull << 25 | 9ull << 30 | 11ull << 35 | 15ull << 40 | 17ull << 45 | 3ull << 50 | 5ull << 55;
+                        constexpr uint64_t w1 = 21ull | 23ull << 5 | 1ull << 10 | 7ull << 15 | 19ull << 20 | 25ull << 25 | 0ull << 30 | 2ull << 35 | 6ull << 40 | 8ull << 45 | 18ull << 50 | 20ull << 55;
+                        constexpr uint64_t w2 = 24ull | 26ull << 5;
+                        const uint64_t w = b < 12u ? w0 : (b < 24u ? w1 : w2);
+                        const uint32_t sh5 = (b < 12u ? b : (b < 24u ? b - 12u : b - 24u)) * 5u;
+                        o = on[t] ? (uint32_t)(w >> sh5) & 31u : 13u;
+                    } else {
+                        constexpr uint64_t w0 = 12ull | 14ull << 5 | 10ull << 10 | 16ull << 15 | 9ull << 20 | 11ull << 25 | 15ull << 30 | 17ull << 35;
+                        o = on[t] ? (uint32_t)(w0 >> (b * 5u)) & 31u : 13u;
                     }
+                    const uint32_t o3 = (o * 11u) >> 5, o9 = (o3 * 11u) >> 5;   // o / 3, o / 9 for o < 27
+                    cc[t][0] = cq[0] + (o - 3u * o3) - 1u;
+                    cc[t][1] = cq[1] + (o3 - 3u * o9) - 1u;
+                    cc[t][2] = cq[2] + o9 - 1u;
+                    block_load(blk, on[t] ? (cc[t][2] * grid.G[1] + cc[t][1]) * grid.G[0] + cc[t][0] : 0u, v[t]);
+                }
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const bool on = cur[r] != kCellEnd;
-                        if (__ballot(on) != 0) {
-                            const float s = on ? cell_s<DIM>(nd[r], tq) : __builtin_inff();
-                            top2_push(t2, s, cur[r]);
-                            cur[r] = on ? lf32_bits(nd[r][3]) : kCellEnd;
-                        }
-                    }
+                for (int t = 0; t < NB; ++t) {
+                    if (__ballot(on[t]) == 0) break;
+                    float off[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) off[k] = ((float)cc[t][k] + 0x1p-17f) - tq[k];
+                    cnt[t] = on[t] ? v[t][0][0] : 0u;
+                    block_eval<DIM>(v[t], cnt[t] < kBlkEntries ? cnt[t] : kBlkEntries, off, t2);
+                    if (__ballot(cnt[t] > kBlkEntries) != 0) chain_follow<DIM>(blk, v[t][0][1], cnt[t], on[t], off, t2);
+                }
+                // what this trip found may rule out cells that were still on the list
+                if (__ballot(need != 0) != 0) {
+                    const double dd = sqrt((double)t2.s1) * (1.0 + 0x1p-20) + 2.0 * A;
+                    const float thr_now = t2.s1 < __builtin_inff() ? f32_up(dd * dd * (1.0 + 0x1p-20)) : __builtin_inff();
+                    need &= needed(thr_now);
                 }
             }
             verdict = cells_verdict(t2, block_lb<DIM>(grid, tq, cq, 1u), A);
+            OXHIP_CPHASE(0);   // own cell + the neighbour cells that matter
             // ---- a lane whose block cannot rule out the cells beyond it: the WAVE searches the next shells for that query
             uint64_t needm = __ballot(act && !from_memo && verdict == 1);
             while (needm != 0) {
@@ -612,13 +740,8 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
                         const int cheb = ax > ay ? (ax > az ? ax : az) : (ay > az ? ay : az);
                         const int cx = (int)cqj[0] + dx, cy = (int)cqj[1] + dy, cz = (int)cqj[2] + dz;
                         if (cheb != (int)r || cx < 0 || cy < 0 || cz < 0 || cx >= (int)grid.G[0] || cy >= (int)grid.G[1] || cz >= (int)grid.G[2]) continue;
-                        uint32_t cur = __hip_atomic_load(&heads[((uint32_t)cz * grid.G[1] + (uint32_t)cy) * grid.G[0] + (uint32_t)cx],
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        while (cur != kCellEnd) {
-                            const cfloat4 nd = nodes[cur];
-                            top2_push(tl, cell_s<DIM>(nd, tqj), cur);
-                            cur = lf32_bits(nd[3]);
-                        }
+                        const uint32_t cs[3] = {(uint32_t)cx, (uint32_t)cy, (uint32_t)cz};
+                        cell_visit<DIM>(blk, ((uint32_t)cz * grid.G[1] + (uint32_t)cy) * grid.G[0] + (uint32_t)cx, true, cs, tqj, tl);
                     }
                     // the shell's two smallest over the wave (binary32 values >= +0 order like their bit patterns)
                     const uint32_t m1 = wave_min_u32(lf32_bits(tl.s1));
@@ -632,7 +755,7 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
                 if (lane == (uint32_t)jl) { t2 = tj; verdict = vj; }
             }
         }
-        OXHIP_CPHASE(0);   // the screen
+        OXHIP_CPHASE(6);   // shell searches
         // ---- the candidate in binary64, exactly as the reference computes it
         uint32_t nearest = (act && verdict == 0) ? t2.i1 : kNoNode;
         double q_near[D];
@@ -847,13 +970,15 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
                 {
                     float tf[3];
                     double err;
-                    const uint32_t cell = cell_place<DIM>(grid, qn, tf, err);
+                    uint64_t entry;
+                    const uint32_t cell = cell_place<DIM>(grid, qn, idx, entry, tf, err);
                     const bool link = mine && ok && !dup;
-                    uint32_t old = kCellEnd;
-                    if (link && grid.level != 0) old = __hip_atomic_exchange(&heads[cell], idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (mine && ok)
-                        nodes[idx] = link ? cfloat4{tf[0], tf[1], tf[2], lbits_f32(old)}
-                                          : cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), lbits_f32(kCellEnd)};
+                    if (grid.level == 0) {
+                        if (mine && ok && idx < kBruteMax)
+                            flat[idx] = link ? cfloat4{tf[0], tf[1], tf[2], 0.0f} : cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f};
+                    } else {
+                        cells_insert(blk, grid.pool_next, cell, entry, link, lane);
+                    }
                     const double e = -wave_min_f64(link ? -err : 0.0);
                     if (e > grid.delta_node) grid.delta_node = (double)f32_up(e * (1.0 + 1e-9));
                     uint32_t mab = 0;
@@ -1001,17 +1126,17 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
                     const uint32_t i = n;
                     float tf[3];
                     double err;
-                    const uint32_t cell = cell_place<DIM>(grid, qn1, tf, err);
+                    uint64_t entry;
+                    const uint32_t cell = cell_place<DIM>(grid, qn1, i, entry, tf, err);
                     if (lane == 0) {
 #pragma unroll
                         for (int k = 0; k < D; ++k) tree[(size_t)k * cap + i] = qn1[k];
                         parent[i] = (int32_t)nearest1;
                         skip[i] = dup1 ? 1 : 0;
-                        uint32_t old = kCellEnd;
-                        if (!dup1 && grid.level != 0) old = __hip_atomic_exchange(&heads[cell], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        nodes[i] = dup1 ? cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), lbits_f32(kCellEnd)}
-                                        : cfloat4{tf[0], tf[1], tf[2], lbits_f32(old)};
+                        if (grid.level == 0 && i < kBruteMax)
+                            flat[i] = dup1 ? cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f} : cfloat4{tf[0], tf[1], tf[2], 0.0f};
                     }
+                    if (grid.level != 0) cells_insert(blk, grid.pool_next, cell, entry, lane == 0 && !dup1, lane);
                     if (!dup1 && err > grid.delta_node) grid.delta_node = (double)f32_up(err * (1.0 + 1e-9));
                     {
                         uint32_t mab = 0;
@@ -1131,14 +1256,19 @@ __global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
     }
 }
 
-bool cells_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && cap <= (1u << 20); }
+bool cells_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && cap <= 65535u; }   // (a block entry names its node with 16 bits)
 
-// grid level a tree of `cap` nodes can reach: the heads array is sized for it
+// grid level a tree of `cap` nodes can reach: the block array is sized for it
 uint32_t cells_level_max(uint32_t dim, uint32_t cap) {
-    uint32_t l = 0;
-    while ((1ull << (dim * (l + 1))) <= (unsigned long long)cap) ++l;
-    const uint32_t lim = dim == 2 ? 7u : 5u;   // at most 128^2 / 32^3 cells: binary32 cell coordinates keep 2^-16 cells or better
-    return l < lim ? l : lim;
+    const uint32_t lim = dim == 2 ? 14u : 10u;   // at most 128^2 / 32^3 cells
+    uint32_t l = 1;
+    while (l < lim && cells_level_cap(l, (int)dim) < cap) ++l;
+    return l;
+}
+// head blocks the finest grid of a capacity needs
+uint32_t cells_head_blocks(uint32_t dim, uint32_t cap) {
+    const uint32_t g = cells_G(cells_level_max(dim, cap));
+    return dim == 2 ? g * g : g * g * g;
 }
 
 template <int DIM>

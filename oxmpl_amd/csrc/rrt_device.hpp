@@ -64,7 +64,15 @@ struct CellMeta {
     uint32_t valid;        // 0 after setup / set_tree
     float delta_node;      // bound on |stored - true| of any node coordinate, cell units
     uint32_t mabs_bits;    // bits of the largest |fl32(coordinate - c0)| over the tree
-    uint32_t pad;
+    uint32_t pool_next;    // next free overflow block
+};
+// one cell of the grid: 64 bytes = one memory sector.  Head blocks are indexed by cell; a cell with more than seven nodes
+// chains overflow blocks (allocated after the head blocks).  Entry = x | y << 16 | z << 32 | node << 48: the node's position
+// inside the cell in 2^-16 cell units (decoded at the bin centre) and its index in the tree.
+struct alignas(64) CellBlock {
+    uint32_t count;   // head block: nodes filed in this cell (all its blocks)
+    uint32_t next;    // next block of the cell's chain (0: none)
+    uint64_t e[7];
 };
 struct CellAcc {
     uint64_t chk, accepted, pos;
@@ -130,12 +138,12 @@ struct DevParams {
     uint32_t goal_sampler;  // oxhip_goal_sampler
     const double* goal_r;   // [P] goal radii as given (the disc sampler scales by them)
     // rrt_cells.hip
-    float* cell_node;        // [P][cap][4]: node i as (tx, ty, tz, next): position in cell units, next node of its cell's list
-    uint32_t* cell_head;     // [P][cell_heads]: first node of every cell's list (0xFFFFFFFF: empty)
+    CellBlock* cell_blk;     // [P][cell_blocks]: head blocks (one per cell of the finest grid), then the overflow blocks
+    float* cell_flat;        // [P][1024][4]: trees of up to 1,024 nodes as a flat list (tx, ty, tz, -): positions in cell units
     CellMeta* cell_meta;     // [P]
     CellAcc* cell_acc;       // [P] zero between launches
     uint64_t* cell_part_pos; // [P][8] stream position at which each part of a split frozen launch starts
-    uint32_t cell_heads, cell_level_max, cells_split;
+    uint32_t cell_blocks, cell_level_max, cells_split;
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }

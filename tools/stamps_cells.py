@@ -10,7 +10,8 @@ from oxmpl_amd import capi, scenarios  # noqa: E402
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 split = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 sc = scenarios.config2()
-names = ["screen (walk / expansions)", "candidate f64 + steer", "sphere filter", "motion check", "prefix (cap, goal, conflicts)", "commit"]
+names = ["own cell + needed neighbour cells", "candidate f64 + steer", "sphere filter", "motion check", "prefix (cap, goal, conflicts)", "commit",
+         "shell searches (cooperative)", "flat scan (trees <= 1024 nodes)"]
 
 
 def show(tag, g, iters):
