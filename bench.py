@@ -366,7 +366,7 @@ def main():
             if not verified:
                 raise SystemExit("bench.py: RRT* (decoupled design) != oracle on problem %d: refusing to report" % first_id)
         secondary_star = {"planner": "RRT* (rrt_star.rs), search radius 1.0, %d trees grown 1 -> %d nodes" % (P, N_NODES),
-                          "design": "decoupled: rrt_lanes.hip + rrt_star_wire.hip" if st_t["kernel"] == capi.KERNEL_LANES else "one kernel: rrt_star.hip",
+                          "design": {capi.KERNEL_CELLS: "decoupled: rrt_cells.hip + rrt_star_wire.hip", capi.KERNEL_LANES: "decoupled: rrt_lanes.hip + rrt_star_wire.hip"}.get(st_t["kernel"], "one kernel: rrt_star.hip"),
                           "iterations": int(st_c["iterations"].sum()), "kernel_ms": st_t["kernel_ms"],
                           "iterations_per_s": float(st_c["iterations"].sum()) / (st_t["kernel_ms"] * 1e-3),
                           "problem0_parents_costs_checksum_equal_oracle": verified}

@@ -45,7 +45,8 @@ struct oxhip_rrt_batch {
     DevBuf<StarEntry> pool;
     DevBuf<StarChunk> chunks;
     DevBuf<uint32_t> chunk_cursor;
-    bool star_wired = false;        // RRT*: geometry by rrt_lanes.hip + the wiring kernels (else rrt_star.hip)
+    bool star_wired = false;        // RRT*: geometry by rrt_lanes.hip / rrt_cells.hip + the wiring kernels (else rrt_star.hip)
+    bool star_geo_cells = false;    // ... by rrt_cells.hip
     hipStream_t stream2 = nullptr;  // RRT*, decoupled: the wiring of a segment runs here while the next segment's pairs are checked on `stream`
     hipEvent_t ev_seg[8] = {}, ev_join = nullptr;
     DevBuf<float> tree32;           // stream / RRT* kernels: fl32 shadow of the tree
@@ -113,15 +114,16 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         return fail(OXHIP_ERR_BAD_ARG, "kernel kinds 3 (box-pruned scan) and 4 (lane-group resolver) were retired in ABI version 2");
     if (cfg->planner > OXHIP_PLANNER_RRT_STAR) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
     if (cfg->frozen_split > 8) return fail(OXHIP_ERR_BAD_ARG, "frozen_split must be 0 (automatic) or 1 .. 8");
-    if (cfg->kernel == OXHIP_KERNEL_CELLS && cfg->planner != OXHIP_PLANNER_RRT)
-        return fail(OXHIP_ERR_BAD_ARG, "the cell-grid kernel runs the RRT planner");
+    if (cfg->kernel == OXHIP_KERNEL_CELLS && cfg->planner == OXHIP_PLANNER_RRT_CONNECT)
+        return fail(OXHIP_ERR_BAD_ARG, "the cell-grid kernel runs RRT, and the geometry of the decoupled RRT*");
     if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
         return fail(OXHIP_ERR_BAD_ARG, "RRTConnect runs on the stream kernel only");
-    // RRT*: KERNEL_STREAM = rrt_star.hip (one workgroup per problem, everything in one kernel); KERNEL_LANES = the decoupled
-    // design (geometry by rrt_lanes.hip, then the wiring kernels of rrt_star_wire.hip); KERNEL_AUTO = the latter where it exists
+    // RRT*: KERNEL_STREAM = rrt_star.hip (one workgroup per problem, everything in one kernel); KERNEL_LANES / KERNEL_CELLS = the
+    // decoupled design (geometry by rrt_lanes.hip / rrt_cells.hip, then the wiring kernels of rrt_star_wire.hip); KERNEL_AUTO = the
+    // decoupled design where it exists, its geometry by rrt_cells.hip in R^2 / R^3
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR && cfg->kernel != OXHIP_KERNEL_AUTO && cfg->kernel != OXHIP_KERNEL_STREAM &&
-        cfg->kernel != OXHIP_KERNEL_LANES)
-        return fail(OXHIP_ERR_BAD_ARG, "RRT* runs on the stream kernel or on the lane-per-query kernel + wiring kernels");
+        cfg->kernel != OXHIP_KERNEL_LANES && cfg->kernel != OXHIP_KERNEL_CELLS)
+        return fail(OXHIP_ERR_BAD_ARG, "RRT* runs on the stream kernel or on the lane-per-query / cell-grid kernel + wiring kernels");
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR && std::isnan(cfg->search_radius))
         return fail(OXHIP_ERR_BAD_ARG, "search_radius is NaN");
     if (cfg->goal_sampler > OXHIP_GOAL_SAMPLE_UNIFORM_DISC) return fail(OXHIP_ERR_BAD_ARG, "unknown goal sampler");
@@ -194,12 +196,15 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         chk(b->parent_b.alloc((size_t)P * cap));
     }
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR) {
-        const bool can_wire = star_wire_supported(dim) && lanes_supported(dim, cap);
-        b->star_wired = cfg->kernel == OXHIP_KERNEL_LANES || (cfg->kernel == OXHIP_KERNEL_AUTO && can_wire);
+        const bool geo_cells = cfg->kernel != OXHIP_KERNEL_LANES && cells_supported(dim, cap);
+        const bool geo_lanes = cfg->kernel != OXHIP_KERNEL_CELLS && lanes_supported(dim, cap);
+        const bool can_wire = star_wire_supported(dim) && (geo_cells || geo_lanes);
+        b->star_wired = cfg->kernel == OXHIP_KERNEL_LANES || cfg->kernel == OXHIP_KERNEL_CELLS || (cfg->kernel == OXHIP_KERNEL_AUTO && can_wire);
         if (b->star_wired && !can_wire) {
             oxhip_rrt_batch_destroy(b);
-            return fail(OXHIP_ERR_BAD_ARG, "decoupled RRT*: the lane-per-query kernel does not support this (dim, max_nodes)");
+            return fail(OXHIP_ERR_BAD_ARG, "decoupled RRT*: neither geometry kernel supports this (dim, max_nodes)");
         }
+        b->star_geo_cells = b->star_wired && geo_cells;
         chk(b->cost.alloc((size_t)P * cap));
         chk(b->wire_chk.alloc(P));
         if (b->star_wired && e == hipSuccess) {
@@ -235,6 +240,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
                 b->nbr_total.release(); b->nbr_cnt.release(); b->nbr_off.release(); b->d_near.release();
                 dp.pool_share = dp.chunk_share = 0;
                 b->star_wired = false;
+                b->star_geo_cells = false;
             } else {
                 chk(ew);
             }
@@ -262,9 +268,9 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.goal_c = b->goal_c.p; dp.goal_thr = b->goal_thr.p; dp.goal_r = b->goal_r.p;
 
     uint32_t kind = cfg->kernel;
-    if (cfg->planner != OXHIP_PLANNER_RRT) kind = b->star_wired ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
+    if (cfg->planner != OXHIP_PLANNER_RRT) kind = b->star_wired ? (b->star_geo_cells ? OXHIP_KERNEL_CELLS : OXHIP_KERNEL_LANES) : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO)
-        kind = lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
+        kind = cells_supported(dim, cap) ? OXHIP_KERNEL_CELLS : lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_CELLS) {
         if (!cells_supported(dim, cap)) {
             oxhip_rrt_batch_destroy(b);
@@ -303,7 +309,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     }
     b->kernel_kind = kind;
     b->last_kind = kind;
-    if ((cfg->planner == OXHIP_PLANNER_RRT && kind == OXHIP_KERNEL_STREAM) || cfg->planner == OXHIP_PLANNER_RRT_STAR) {
+    if ((cfg->planner == OXHIP_PLANNER_RRT && kind == OXHIP_KERNEL_STREAM) || cfg->planner == OXHIP_PLANNER_RRT_STAR) {   // (RRT*: star_shadow's)
         // the streaming kernels screen their scans over an fl32 shadow of the tree, which they maintain themselves
         hipError_t e2 = b->tree32.alloc((size_t)P * dim * cap);
         if (e2 == hipSuccess) e2 = b->shadow_state.alloc((size_t)P * 2);
@@ -650,7 +656,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR && b->star_wired) {
             // geometry: exactly RRT's loop on the same stream (rrt_star_wire.hip's header); then wire the new nodes
-            launch_rrt_lanes(b->dp, b->stream);
+            if (b->star_geo_cells) launch_rrt_cells(b->dp, b->stream); else launch_rrt_lanes(b->dp, b->stream);
             HIP_TRY(hipGetLastError());
             if ((st = wire_new_nodes(b)) != OXHIP_OK) return st;
         }

@@ -1200,11 +1200,14 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
         atomicAdd((unsigned long long*)&p.dbg[60], (unsigned long long)n_expand);
         atomicAdd((unsigned long long*)&p.dbg[61], (unsigned long long)n_regrid);
         atomicAdd((unsigned long long*)&p.dbg[45], (unsigned long long)n_amb);
-        if (prob == 0 && part == 0) {
-            p.dbg[4] = n_amb; p.dbg[5] = n_rounds; p.dbg[6] = n_lanes; p.dbg[7] = st.iterations; p.dbg[12] = n_cut_conflict;
-            p.dbg[15] = n_tie; p.dbg[11] = n_memo; p.dbg[8] = n_expand; p.dbg[9] = n_steps; p.dbg[10] = n_regrid;
-            for (int i = 0; i < 8; ++i) p.dbg[32 + i] = t_ph[i];
-            p.dbg[13] = (uint64_t)clock64() - t_begin;
+        if (prob == 0) {   // problem 0, summed over the parts of a split launch (and over the launches since enable_stamps)
+            const uint64_t vals[8] = {n_amb, n_rounds, n_lanes, st.iterations, n_expand, n_steps, n_regrid, n_memo};
+            const int idx[8] = {4, 5, 6, 7, 8, 9, 10, 11};
+            for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&p.dbg[idx[i]], (unsigned long long)vals[i]);
+            atomicAdd((unsigned long long*)&p.dbg[12], (unsigned long long)n_cut_conflict);
+            atomicAdd((unsigned long long*)&p.dbg[15], (unsigned long long)n_tie);
+            for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&p.dbg[32 + i], (unsigned long long)t_ph[i]);
+            atomicAdd((unsigned long long*)&p.dbg[13], (unsigned long long)((uint64_t)clock64() - t_begin));
         }
     }
 }

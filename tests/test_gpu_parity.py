@@ -18,17 +18,17 @@ from oxmpl_amd import capi, scenarios  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
 
 # KERNEL_AUTO = what a user gets (the lane-per-query kernel where it exists); KERNEL_RESIDENT = the all-binary64 cross-check
-KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_LANES, capi.KERNEL_AUTO]
-KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_LANES: "lanes", capi.KERNEL_AUTO: "auto"}
-SCREENED = (capi.KERNEL_LANES,)   # kernels that count their exact-path events (stamps()[4])
+KERNELS = [capi.KERNEL_STREAM, capi.KERNEL_RESIDENT, capi.KERNEL_LANES, capi.KERNEL_CELLS, capi.KERNEL_AUTO]
+KNAME = {capi.KERNEL_STREAM: "stream", capi.KERNEL_RESIDENT: "resident", capi.KERNEL_LANES: "lanes", capi.KERNEL_CELLS: "cells", capi.KERNEL_AUTO: "auto"}
+SCREENED = (capi.KERNEL_LANES, capi.KERNEL_CELLS)   # kernels that count their exact-path events (stamps()[4])
 
 
 def _batch_or_skip(*args, **kw):
     try:
         return capi.RRTBatch(*args, **kw)
     except capi.OxhipError as e:
-        if e.status == capi.ERR_BAD_ARG and "resident" in str(e):
-            pytest.skip("resident kernel has no instantiation for this shape")
+        if e.status == capi.ERR_BAD_ARG and ("resident" in str(e) or "cell-grid kernel" in str(e)):
+            pytest.skip("this kernel has no instantiation for this shape")
         raise
 
 
@@ -47,8 +47,8 @@ def _gpu_for(sc, n_problems, max_nodes, stop, seed, first_pid=0, kernel=0):
     try:
         return scenarios.make_batch(sc, n_problems, max_nodes, stop, seed, first_pid, 0, kernel)
     except capi.OxhipError as e:
-        if e.status == capi.ERR_BAD_ARG and "resident" in str(e):
-            pytest.skip("resident kernel has no instantiation for this shape")
+        if e.status == capi.ERR_BAD_ARG and ("resident" in str(e) or "cell-grid kernel" in str(e)):
+            pytest.skip("this kernel has no instantiation for this shape")
         raise
 
 
@@ -294,7 +294,7 @@ def test_rrt_large_row_instantiations(kernel, dim, max_nodes):
     gpu.solve(700, freeze=True)
     c = gpu.counts()
     assert (c["nodes"] == max_nodes).all()
-    assert gpu.last_timing()["kernel"] == capi.KERNEL_LANES
+    assert gpu.last_timing()["kernel"] == (capi.KERNEL_LANES if kernel == capi.KERNEL_LANES else capi.KERNEL_CELLS)   # (what AUTO runs in R^2 / R^3)
     planners = [_oracle_for(sc, 11, 40 + p, max_nodes, False) for p in range(P)]
     orc.solve_many(planners, 10 ** 7, threads=3)
     orc.solve_many(planners, 700, freeze=True, threads=3)
@@ -322,6 +322,8 @@ def test_rrt_other_dimensions_and_obstacle_mixes(kernel):
             continue  # these resident kernels are instantiated for R^2 / R^3 only
         if kernel == capi.KERNEL_LANES and dim not in (2, 3, 4, 5, 6):
             continue  # the lane-per-query kernel: R^2 .. R^6
+        if kernel == capi.KERNEL_CELLS and dim not in (2, 3):
+            continue  # the cell-grid kernel: R^2, R^3
         gpu = _gpu_for(sc, P, 400, False, 7, 100, kernel)
         gpu.solve(500)
         planners = [_oracle_for(sc, 7, 100 + p, 400, False) for p in range(P)]

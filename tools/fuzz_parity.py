@@ -57,13 +57,13 @@ def case_rv(planner):
     radius = float(rng.choice([0.0, 0.05, 0.15, 0.5])) * w
     kernels = [capi.KERNEL_STREAM]
     if planner == capi.PLANNER_RRT and dim in (2, 3):
-        kernels += [capi.KERNEL_RESIDENT]
+        kernels += [capi.KERNEL_RESIDENT, capi.KERNEL_CELLS, capi.KERNEL_CELLS]
     if planner == capi.PLANNER_RRT and 2 <= dim <= 6:
         kernels += [capi.KERNEL_LANES, capi.KERNEL_LANES, capi.KERNEL_AUTO]   # the default path: weighted up
     if planner == capi.PLANNER_RRT_STAR and 2 <= dim <= 6:
-        kernels += [capi.KERNEL_AUTO, capi.KERNEL_AUTO]   # RRT*: the decoupled design (rrt_lanes.hip + rrt_star_wire.hip) where it exists
+        kernels += [capi.KERNEL_AUTO, capi.KERNEL_AUTO, capi.KERNEL_LANES]   # RRT*: the decoupled design (geometry by rrt_cells.hip / rrt_lanes.hip + rrt_star_wire.hip)
     kernel = int(rng.choice(kernels))
-    flags = int(rng.choice(LANE_FLAGS)) if (kernel in (capi.KERNEL_LANES, capi.KERNEL_AUTO) and planner != capi.PLANNER_RRT_CONNECT) else 0
+    flags = int(rng.choice(LANE_FLAGS)) if (kernel in (capi.KERNEL_LANES, capi.KERNEL_CELLS, capi.KERNEL_AUTO) and planner != capi.PLANNER_RRT_CONNECT) else 0
     if flags & capi.DEBUG_ALL_WHOLE_TREE:   # every query scans the whole tree with one wave: keep those cases short
         iters, max_nodes = min(iters, 3000), min(max_nodes, 2500)
     desc = dict(planner=planner, kernel=kernel, dim=dim, lo=lo, hi=hi, md=md, gb=gb, frac=frac, ns=len(sr), nb=len(blo),
@@ -71,7 +71,8 @@ def case_rv(planner):
     if planner == capi.PLANNER_RRT_CONNECT:
         stop = True
     try:
-        g = capi.RRTBatch(dim, bounds, md, gb, nprob, max_nodes, frac, stop, seed, pid0, 0, kernel, planner, radius, debug_flags=flags)
+        g = capi.RRTBatch(dim, bounds, md, gb, nprob, max_nodes, frac, stop, seed, pid0, 0, kernel, planner, radius, debug_flags=flags,
+                          frozen_split=int(rng.choice([0, 0, 1, 3, 8])))
     except capi.OxhipError as e:
         if e.status == capi.ERR_BAD_ARG:
             return None
@@ -97,6 +98,9 @@ def case_rv(planner):
     frozen = int(rng.choice([0, 0, 64, 700, 3000])) if planner == capi.PLANNER_RRT else 0   # then some iterations with inserts off
     if frozen:
         g.solve(frozen, freeze=True)
+        if rng.random() < 0.3:
+            g.solve(37, freeze=True)
+            frozen += 37
     c = g.counts()
     for p in range(nprob):
         if planner == capi.PLANNER_RRT:

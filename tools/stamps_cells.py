@@ -30,6 +30,6 @@ g = scenarios.make_batch(sc, P, 10000, False, 42, 0, 0, capi.KERNEL_CELLS, froze
 g.enable_stamps(True)
 g.solve(10 ** 7)
 show("grow 1 -> 10,000 nodes", g, int(g.counts()["iterations"][0]))
-g.enable_stamps(True)
+g.enable_stamps(True)   # (re-zeroes the counters)
 g.solve(4096, freeze=True)
 show("steady@10k, 4096 iterations, split %d (part 0 of problem 0)" % split, g, 4096 // split)
