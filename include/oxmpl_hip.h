@@ -274,7 +274,8 @@ int32_t oxhip_rrt_batch_check_motion(oxhip_rrt_batch* b, const double* from, con
                                      uint32_t n, uint8_t* out);
 
 /* device arithmetic self-test hooks: out[i] = op(a[i], b[i]) computed on the GPU.
- * op: 0 sqrt(a), 1 a/b, 2 ceil(a), 3 a + (b - a) * t (t = c[i], unfused), 4 (a-b)*(a-b) */
+ * op: 0 sqrt(a), 1 a/b, 2 ceil(a), 3 a + (b - a) * t (t = c[i], unfused), 4 (a-b)*(a-b),
+ *     5 / 6: sin(a) / cos(a) as the disc goal sampler evaluates them (ox_sincos; 0 <= a < 2^19 pi/2) */
 int32_t oxhip_f64_op_batch(int32_t device, uint32_t op, const double* a, const double* b,
                            const double* c, uint32_t n, double* out);
 /* SO(2) / SE(2) arithmetic self-test hooks, n rows of (x, y, theta):

@@ -63,6 +63,9 @@ def lib():
         L.orc_rrt_set_spheres.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
         L.orc_rrt_set_boxes.argtypes = [C.c_void_p, _dp, _dp, C.c_uint32]
         L.orc_rrt_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
+        L.orc_rrt_set_goal_sampler.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_sincos_libm.argtypes = [C.c_int]
+        L.orc_sincos.argtypes = [C.c_double, _dp, _dp]
         L.orc_rrt_set_tree.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int32), C.c_uint32]
         L.orc_rrt_solve.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_double]
         L.orc_rrt_num_nodes.argtypes = [C.c_void_p]
@@ -270,6 +273,12 @@ class OracleRRT:
         s, ps = _d(start)
         g, pg = _d(goal_centre)
         return lib().orc_rrt_setup(self.h, ps, pg, goal_radius)
+
+    def set_goal_sampler(self, mode):
+        """0: sample_goal() = the centre (no draw); 1: uniform in the disc (rrt_rvss_tests.rs:55-66, R^2).  Also for RRT*."""
+        st = lib().orc_rrt_set_goal_sampler(self.h, int(mode))
+        if st != 0:
+            raise ValueError("orc_rrt_set_goal_sampler failed with status %d" % st)
 
     def set_tree(self, states, parents):
         s, ps = _d(np.asarray(states, dtype=np.float64).reshape(-1, self.dim))
@@ -602,3 +611,14 @@ class OracleSE2Connect:
         a, pa = _d(a)
         b, pb = _d(b)
         return bool(lib().orc_se2c_check_motion(self.h, pa, pb))
+
+
+def sincos(x):
+    """(sin, cos) as the disc goal sampler computes them (ox_sincos, or libm after set_sincos_libm(True))"""
+    s, c = C.c_double(), C.c_double()
+    lib().orc_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def set_sincos_libm(use_libm):
+    lib().orc_set_sincos_libm(int(bool(use_libm)))

@@ -12,6 +12,7 @@
  */
 #define _POSIX_C_SOURCE 200809L
 #include "rrt_oracle.h"
+#include "ox_sincos.h"
 
 #include <math.h>
 #include <pthread.h>
@@ -199,6 +200,7 @@ struct orc_rrt {
     orc_checker checker;
     int is_setup;
     double goal_centre[ORC_MAX_DIM];
+    int goal_sampler;   /* 0: sample_goal() = centre, no draw; 1: uniform in the disc, rrt_rvss_tests.rs:55-66 */
     double goal_radius;
     orc_node* tree;
     uint32_t n, cap;
@@ -312,6 +314,38 @@ static void push_node(orc_rrt* r, const double* state, int64_t parent) {
 
 /* rrt.rs:140-156: clear the tree, push start_states[0] with parent None.
  * Start validity is NOT checked (reference behaviour). */
+/* GoalSampleableRegion::sample_goal of the ball goal (goal.rs:35-41).  Mode 0: the centre, nothing drawn (README.md:160-162).
+ * Mode 1, the reference's own test fixture (oxmpl/tests/rrt_rvss_tests.rs:55-66, R^2):
+ *     let angle = rng.random_range(0.0..2.0 * PI);
+ *     let radius = self.radius * rng.random::<f64>().sqrt();      -- rand 0.9 StandardUniform f64: (u64 >> 11) * 2^-53
+ *     x = target[0] + radius * angle.cos();  y = target[1] + radius * angle.sin();
+ * cos / sin through ox_sincos (the routine the device runs too) or, for comparison, this host's libm. */
+static int g_sincos_libm = 0;
+void orc_set_sincos_libm(int use_libm) { g_sincos_libm = use_libm; }
+void orc_sincos(double x, double* s, double* c) {
+    if (g_sincos_libm) { *s = sin(x); *c = cos(x); } else ox_sincos(x, s, c);
+}
+static void sample_goal(orc_rrt* r, double* q) {
+    if (r->goal_sampler == 0) {
+        memcpy(q, r->goal_centre, sizeof(double) * r->dim);
+        return;
+    }
+    const double two_pi = 2.0 * 3.14159265358979323846;   /* 2.0 * std::f64::consts::PI */
+    const double angle = orc_random_range(&r->rng, 0.0, two_pi);
+    const double u01 = (double)(orc_rng_next_u64(&r->rng) >> 11) * 0x1p-53;
+    const double radius = r->goal_radius * sqrt(u01);
+    double sn, cs;
+    orc_sincos(angle, &sn, &cs);
+    const double rx = radius * cs, ry = radius * sn;
+    q[0] = r->goal_centre[0] + rx;
+    q[1] = r->goal_centre[1] + ry;
+}
+int orc_rrt_set_goal_sampler(orc_rrt* r, int mode) {
+    if (!r || mode < 0 || mode > 1 || (mode == 1 && r->dim != 2)) return ORC_BAD_ARG;
+    r->goal_sampler = mode;
+    return 0;
+}
+
 int orc_rrt_setup(orc_rrt* r, const double* start, const double* goal_centre, double goal_radius) {
     clear_tree(r);
     memcpy(r->goal_centre, goal_centre, sizeof(double) * r->dim);
@@ -396,7 +430,7 @@ int orc_rrt_solve(orc_rrt* r, uint64_t max_iterations, int freeze, double timeou
         /* 2. sample (rrt.rs:177-184) */
         double* q_rand = (double*)malloc(sizeof(double) * dim);
         if (orc_random_bool(&r->rng, r->goal_bias)) {
-            memcpy(q_rand, r->goal_centre, sizeof(double) * dim); /* sample_goal = centre */
+            sample_goal(r, q_rand);
         } else {
             for (uint32_t k = 0; k < dim; ++k) /* rvss.rs:236-246 */
                 q_rand[k] = orc_random_range(&r->rng, r->bounds[2 * k], r->bounds[2 * k + 1]);
@@ -556,7 +590,7 @@ int orc_rrts_solve(orc_rrts* r, uint64_t max_iterations, double timeout_s) {
         /* 2. sample (:180-187) */
         double* q_rand = (double*)malloc(sizeof(double) * dim);
         if (orc_random_bool(&a->rng, a->goal_bias)) {
-            memcpy(q_rand, a->goal_centre, sizeof(double) * dim);
+            sample_goal(a, q_rand);
         } else {
             for (uint32_t k = 0; k < dim; ++k) q_rand[k] = orc_random_range(&a->rng, a->bounds[2 * k], a->bounds[2 * k + 1]);
         }

@@ -83,6 +83,12 @@ int orc_rrt_set_spheres(orc_rrt* r, const double* centres, const double* radii, 
 int orc_rrt_set_boxes(orc_rrt* r, const double* lo, const double* hi, uint32_t n);
 /* Planner::setup (rrt.rs:140-156) with a ball goal whose sample_goal() is the centre */
 int orc_rrt_setup(orc_rrt* r, const double* start, const double* goal_centre, double goal_radius);
+/* GoalSampleableRegion::sample_goal (goal.rs:35-41): 0 = the centre, no draw (README.md:160-162); 1 = uniform in the disc as the
+ * reference's test fixtures sample it (rrt_rvss_tests.rs:55-66; dim must be 2).  Applies to RRT and RRT* (orc_rrts_base). */
+int orc_rrt_set_goal_sampler(orc_rrt* r, int mode);
+/* sin / cos of the disc sampler: ox_sincos (default: the portable routine the device runs too) or this host's libm */
+void orc_set_sincos_libm(int use_libm);
+void orc_sincos(double x, double* s, double* c);
 /* warm start: replace the tree by n nodes (AoS states, parents[0] = -1); counters / RNG untouched */
 int orc_rrt_set_tree(orc_rrt* r, const double* states, const int32_t* parents, uint32_t n);
 /* Planner::solve (rrt.rs:158-227) with a deterministic iteration budget.

@@ -129,6 +129,8 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (cfg->goal_sampler > OXHIP_GOAL_SAMPLE_UNIFORM_DISC) return fail(OXHIP_ERR_BAD_ARG, "unknown goal sampler");
     if (cfg->goal_sampler == OXHIP_GOAL_SAMPLE_UNIFORM_DISC && (cfg->dim != 2 || cfg->space != OXHIP_SPACE_REAL_VECTOR))
         return fail(OXHIP_ERR_BAD_ARG, "the disc sampler (rrt_rvss_tests.rs:55-66) is defined for RealVectorStateSpace(2)");
+    if (cfg->goal_sampler == OXHIP_GOAL_SAMPLE_UNIFORM_DISC && (cfg->planner == OXHIP_PLANNER_RRT_CONNECT || cfg->kernel == OXHIP_KERNEL_RESIDENT))
+        return fail(OXHIP_ERR_BAD_ARG, "the disc sampler is built for RRT / RRT* on the stream, lane-per-query and cell-grid kernels");
     double fraction = cfg->lvs_fraction, res = 0.0;
     double th_lo = 0.0, th_hi = 0.0;
     if (cfg->space > OXHIP_SPACE_SE2) return fail(OXHIP_ERR_BAD_ARG, "unknown space kind");
@@ -998,7 +1000,7 @@ int32_t oxhip_rrt_batch_check_motion(oxhip_rrt_batch* b, const double* from, con
 
 int32_t oxhip_f64_op_batch(int32_t device, uint32_t op, const double* a, const double* b, const double* c, uint32_t n,
                            double* out) {
-    if (!a || !out || op > 4) return fail(OXHIP_ERR_BAD_ARG, "bad argument");
+    if (!a || !out || op > 6) return fail(OXHIP_ERR_BAD_ARG, "bad argument");
     if ((op == 1 || op == 3 || op == 4) && !b) return fail(OXHIP_ERR_BAD_ARG, "operand b required");
     if (op == 3 && !c) return fail(OXHIP_ERR_BAD_ARG, "operand c required");
     if (n == 0) return OXHIP_OK;

@@ -263,7 +263,7 @@ __device__ __forceinline__ void grid_store(CellMeta& m, const CellGrid& g, uint3
 // rrt_resident_common.hpp with this kernel's ring).  STORE = false only advances the stream position (the fast-forward of
 // cells_prepare_kernel).  Returns false, nothing written, when a range draw was rejected or the window is too short.
 template <int DIM, bool STORE>
-__device__ __forceinline__ bool cells_sample(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane,
+__device__ __forceinline__ bool cells_sample(RngWindow& rng, const DevParams& p, const double* goal_c, double goal_radius, uint32_t m, uint32_t lane,
                                              CellsWaveLds<DIM>* sh, uint32_t js) {
     const uint64_t win_lo = rng.base_blk * 8;
     const uint64_t pos0 = rng.pos;
@@ -271,16 +271,18 @@ __device__ __forceinline__ bool cells_sample(RngWindow& rng, const DevParams& p,
     const uint32_t rel0 = (uint32_t)(pos0 - win_lo);
     const bool act = lane < m;
     const bool always_goal = p.p_int == ~0ull;
+    const bool disc = DIM == 2 && p.goal_sampler == OXHIP_GOAL_SAMPLE_UNIFORM_DISC;
+    const uint32_t gw = disc ? 2u : 0u;   // words a goal sample draws after its Bernoulli word
     auto word = [&](uint32_t rel) -> uint64_t {
         const uint32_t a = rel0 + rel, bl = a >> 3, w = (a & 7u) * 2u;
         return ((uint64_t)rng.buf[w + 1][bl] << 32) | rng.buf[w][bl];
     };
     uint64_t goal_mask = always_goal ? ~0ull : 0ull;
-    uint32_t off = 0;
+    uint32_t off = act ? gw * lane : 0u;   // (every query is a goal sample: gw words each)
     if (!always_goal) {
         const uint64_t below = below_mask(lane);
         for (uint32_t round = 0; round <= m; ++round) {
-            off = act ? (1u + DIM) * lane - (uint32_t)DIM * (uint32_t)__popcll(goal_mask & below) : 0u;
+            off = act ? (1u + DIM) * lane - ((uint32_t)DIM - gw) * (uint32_t)__popcll(goal_mask & below) : 0u;
             const uint64_t now = __ballot(act && word(off) < p.p_int);
             if (now == goal_mask) break;
             goal_mask = now;
@@ -298,8 +300,15 @@ __device__ __forceinline__ bool cells_sample(RngWindow& rng, const DevParams& p,
         redraw = redraw || !(res < p.hi[k]);
         q[k] = goal ? goal_c[k] : res;
     }
-    if (__ballot(act && !goal && redraw) != 0) return false;
-    const uint32_t cnt = always_goal ? 0u : (goal ? 1u : 1u + (uint32_t)DIM);
+    redraw = redraw && !goal;
+    if (DIM == 2 && disc) {   // the disc sampler's two words follow the Bernoulli word (if one was drawn)
+        const uint32_t base = act && goal ? off + (always_goal ? 0u : 1u) : 0u;
+        double gx, gy;
+        const bool okd = goal_disc_sample(word(base), word(base + 1u), goal_c, goal_radius, gx, gy);
+        if (goal) { q[0] = gx; q[DIM >= 2 ? 1 : 0] = gy; redraw = !okd; }
+    }
+    if (__ballot(act && redraw) != 0) return false;
+    const uint32_t cnt = always_goal ? gw : (goal ? 1u + gw : 1u + (uint32_t)DIM);
     if (STORE && act) {
         const uint32_t slot = (js + lane) & 63u;
 #pragma unroll
@@ -312,7 +321,7 @@ __device__ __forceinline__ bool cells_sample(RngWindow& rng, const DevParams& p,
 
 // draw (STORE) or skip the queries [js, js + m): window refill, the lane-parallel sampler, the sequential fallback
 template <int DIM, bool STORE>
-__device__ __forceinline__ void cells_sample_block(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane,
+__device__ __forceinline__ void cells_sample_block(RngWindow& rng, const DevParams& p, const double* goal_c, double goal_radius, uint32_t m, uint32_t lane,
                                                    CellsWaveLds<DIM>* sh, uint32_t js) {
     const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + DIM) + 64;
     if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
@@ -322,10 +331,10 @@ __device__ __forceinline__ void cells_sample_block(RngWindow& rng, const DevPara
 #pragma unroll
         for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
     }
-    if (!cells_sample<DIM, STORE>(rng, p, goal_c, m, lane, sh, js)) {
+    if (!cells_sample<DIM, STORE>(rng, p, goal_c, goal_radius, m, lane, sh, js)) {
         for (uint32_t b = 0; b < m; ++b) {   // (never expected) a redraw, or a batch past the window: one by one
             double qn[DIM];
-            sample_state<DIM, false>(rng, p, DIM, goal_c, qn);
+            sample_state<DIM, false>(rng, p, DIM, goal_c, qn, goal_radius);
             if (STORE && lane == 0) {
                 const uint32_t slot = (js + b) & 63u;
 #pragma unroll
@@ -436,8 +445,11 @@ __device__ __forceinline__ int cells_verdict(const Top2& t, double lb, double A)
     return 0;
 }
 
+#ifndef OXHIP_CELLS_WAVES_PER_EU
+#define OXHIP_CELLS_WAVES_PER_EU 2
+#endif
 template <int DIM, bool STAMP>
-__global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p) {
+__global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rrt_cells_kernel(DevParams p) {
     constexpr int D = DIM;
     __shared__ CellsShared<DIM> shared;
 
@@ -520,6 +532,7 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
 #pragma unroll
     for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
     const double goal_thr = p.goal_thr[prob];
+    const double goal_radius = p.goal_r[prob];   // (the disc goal sampler scales by it)
 
     // this wave's share of the launch: iterations [j_lo, j_hi) of the problem's budget
     const uint32_t budget_all = (uint32_t)p.budget;
@@ -576,7 +589,7 @@ __global__ __launch_bounds__(kCellsWaves * 64) void rrt_cells_kernel(DevParams p
         }
         uint32_t m = budget - jr < 64u ? budget - jr : 64u;
         if (js < jr + m) {   // draw the queries this round still lacks (rrt.rs:177-184): they depend on the stream only
-            cells_sample_block<DIM, true>(rng, p, goal_c, jr + m - js, lane, sh, js);
+            cells_sample_block<DIM, true>(rng, p, goal_c, goal_radius, jr + m - js, lane, sh, js);
             js = jr + m;
         }
         if (STAMP) { ++n_rounds; n_lanes += m; t_pm = (uint64_t)clock64(); }
@@ -1251,7 +1264,7 @@ __global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
         }
         if (next_part >= split) break;
         const uint32_t m = budget - r * 64u < 64u ? budget - r * 64u : 64u;
-        cells_sample_block<DIM, false>(rng, p, goal_c, m, lane, &shw, r * 64u);
+        cells_sample_block<DIM, false>(rng, p, goal_c, p.goal_r[prob], m, lane, &shw, r * 64u);
     }
     while (next_part < split) {   // (parts without a round start where the stream ends)
         if (lane == 0) p.cell_part_pos[(size_t)prob * 8u + next_part] = rng.pos;

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/oxmpl_hip.h"   // the enums the kernels share with the boundary (debug flags, goal sampler)
+#include "ox_sincos.hpp"
 
 namespace oxhip {
 
@@ -220,15 +221,51 @@ struct RngWindow {
     }
 };
 
+// GoalSampleableRegion::sample_goal of the disc fixture (oxmpl/tests/rrt_rvss_tests.rs:55-66) from its two words:
+//   angle = rng.random_range(0.0..2.0 * PI)  (52-bit transform, res = v01 * scale + lo);  radius = self.radius * rng.random::<f64>().sqrt()
+//   (StandardUniform f64: (u64 >> 11) * 2^-53);  (x, y) = (cx + radius * cos, cy + radius * sin) through ox_sincos.
+// Returns false when the range draw has to be repeated (res >= hi, probability ~2^-53).
+__device__ __forceinline__ bool goal_disc_sample(uint64_t w_angle, uint64_t w_radius, const double* goal_c, double goal_radius, double& x, double& y) {
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    const double v01 = __longlong_as_double((long long)((w_angle >> 12) | 0x3FF0000000000000ull)) - 1.0;
+    double angle = v01 * two_pi;
+    angle = angle + 0.0;
+    const double u01 = (double)(w_radius >> 11) * 0x1p-53;
+    const double radius = goal_radius * sqrt(u01);
+    double sn, cs;
+    ox_sincos(angle < two_pi ? angle : 0.0, sn, cs);
+    const double rx = radius * cs, ry = radius * sn;
+    x = goal_c[0] + rx;
+    y = goal_c[1] + ry;
+    return angle < two_pi;
+}
+
 // rrt.rs:177-184 + real_vector_state_space.rs:233-249 with rand 0.9's transforms.
-// Returns true when the goal was sampled (q = goal centre, no further draw).
+// Returns true when the goal was sampled (oxhip_goal_sampler: q = the goal centre and no further draw, or the disc sampler).
 template <int D, bool WG_SYNC = true>
 __device__ __forceinline__ bool sample_state(RngWindow& rng, const DevParams& p, int dim, const double* goal_c,
-                                             double q[D]) {
+                                             double q[D], double goal_radius = 0.0) {
     bool goal;
     if (p.p_int == ~0ull) goal = true;            // Bernoulli ALWAYS_TRUE: no draw
     else goal = rng.next<WG_SYNC>() < p.p_int;    // one u64
     if (goal) {
+        if (D >= 2 && p.goal_sampler == OXHIP_GOAL_SAMPLE_UNIFORM_DISC) {
+            for (;;) {
+                const uint64_t wa = rng.next<WG_SYNC>();
+                // (random_range redraws only the angle's word; the radius word is drawn after the angle was accepted)
+                const double v01 = __longlong_as_double((long long)((wa >> 12) | 0x3FF0000000000000ull)) - 1.0;
+                double angle = v01 * (2.0 * 3.14159265358979323846);
+                angle = angle + 0.0;
+                if (!(angle < 2.0 * 3.14159265358979323846)) continue;
+                const uint64_t wr = rng.next<WG_SYNC>();
+                double x, y;
+                goal_disc_sample(wa, wr, goal_c, goal_radius, x, y);
+                q[0] = x;
+                q[D >= 2 ? 1 : 0] = y;
+                break;
+            }
+            return true;
+        }
 #pragma unroll
         for (int k = 0; k < D; ++k) if (k < dim) q[k] = goal_c[k];
         return true;

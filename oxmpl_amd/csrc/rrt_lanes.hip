@@ -160,7 +160,7 @@ struct LanesShared {
 // Lane-parallel sampling of m <= 64 consecutive queries into the coordinate-major ring: sample_batch of
 // rrt_resident_common.hpp (rrt.rs:177-184 + rvss.rs:233-249) with this kernel's ring layout and the fl32 copies.
 template <int DIM>
-__device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p, const double* goal_c, const double* c0, uint32_t m,
+__device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p, const double* goal_c, double goal_radius, const double* c0, uint32_t m,
                                              uint32_t lane, LanesShared<DIM>& sh, uint32_t js) {
     const uint64_t win_lo = rng.base_blk * 8;
     const uint64_t pos0 = rng.pos;
@@ -168,16 +168,18 @@ __device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p,
     const uint32_t rel0 = (uint32_t)(pos0 - win_lo);
     const bool act = lane < m;
     const bool always_goal = p.p_int == ~0ull;
+    const bool disc = DIM == 2 && p.goal_sampler == OXHIP_GOAL_SAMPLE_UNIFORM_DISC;
+    const uint32_t gw = disc ? 2u : 0u;   // words a goal sample draws after its Bernoulli word
     auto word = [&](uint32_t rel) -> uint64_t {
         const uint32_t a = rel0 + rel, bl = a >> 3, w = (a & 7u) * 2u;
         return ((uint64_t)rng.buf[w + 1][bl] << 32) | rng.buf[w][bl];
     };
     uint64_t goal_mask = always_goal ? ~0ull : 0ull;
-    uint32_t off = 0;
+    uint32_t off = act ? gw * lane : 0u;   // (every query is a goal sample: gw words each)
     if (!always_goal) {
         const uint64_t below = below_mask(lane);
         for (uint32_t round = 0; round <= m; ++round) {
-            off = act ? (1u + DIM) * lane - (uint32_t)DIM * (uint32_t)__popcll(goal_mask & below) : 0u;
+            off = act ? (1u + DIM) * lane - ((uint32_t)DIM - gw) * (uint32_t)__popcll(goal_mask & below) : 0u;
             const uint64_t now = __ballot(act && word(off) < p.p_int);
             if (now == goal_mask) break;
             goal_mask = now;
@@ -195,8 +197,15 @@ __device__ __forceinline__ bool sample_lanes(RngWindow& rng, const DevParams& p,
         redraw = redraw || !(res < p.hi[k]);
         q[k] = goal ? goal_c[k] : res;
     }
-    if (__ballot(act && !goal && redraw) != 0) return false;
-    const uint32_t cnt = always_goal ? 0u : (goal ? 1u : 1u + (uint32_t)DIM);
+    redraw = redraw && !goal;
+    if (DIM == 2 && disc) {   // the disc sampler's two words follow the Bernoulli word (if one was drawn)
+        const uint32_t base = act && goal ? off + (always_goal ? 0u : 1u) : 0u;
+        double gx, gy;
+        const bool okd = goal_disc_sample(word(base), word(base + 1u), goal_c, goal_radius, gx, gy);
+        if (goal) { q[0] = gx; q[DIM >= 2 ? 1 : 0] = gy; redraw = !okd; }
+    }
+    if (__ballot(act && redraw) != 0) return false;
+    const uint32_t cnt = always_goal ? gw : (goal ? 1u + gw : 1u + (uint32_t)DIM);
     if (act) {
         const uint32_t slot = (js + lane) & (kQRing - 1);
 #pragma unroll
@@ -479,6 +488,7 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
         double goal_c[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
+        const double goal_radius = p.goal_r[prob];   // (the disc goal sampler scales by it)
         __syncthreads();  // the launch's second barrier (see the scanners)
         // while a tree grows everybody downstream waits for this wave: never queue behind the two scanner waves of this SIMD.
         // (Not in the steady measurement: ChaCha12 and the draws are ~10 instructions per query, and at top priority they
@@ -524,10 +534,10 @@ __global__ __launch_bounds__(kLanesThreads) void rrt_lanes_kernel(DevParams p) {
 #pragma unroll
                 for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
             }
-            if (!sample_lanes<DIM>(rng, p, goal_c, c0, m, lane, sh, js)) {
+            if (!sample_lanes<DIM>(rng, p, goal_c, goal_radius, c0, m, lane, sh, js)) {
                 for (uint32_t b = 0; b < m; ++b) {  // (never expected) a redraw ran past the window: one by one
                     double qn[D];
-                    sample_state<D, false>(rng, p, DIM, goal_c, qn);
+                    sample_state<D, false>(rng, p, DIM, goal_c, qn, goal_radius);
                     const uint32_t slot = (js + b) & (kQRing - 1);
                     if (lane == 0) {
 #pragma unroll

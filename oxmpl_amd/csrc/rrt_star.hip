@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kStarThreads, DIM ? 4 : 1) void rrt_star_kernel(Dev
 
         // 2. sample (rrt_star.rs:178-186)
         double q[D];
-        sample_state<D>(rng, p, dim, goal_c, q);
+        sample_state<D>(rng, p, dim, goal_c, q, p.goal_r[prob]);
 
         // 3. nearest (rrt_star.rs:189-199): binary32 screen first (see rrt_stream.hip), else d2 compare with the
         //    exact post-sqrt fallback on near-ties

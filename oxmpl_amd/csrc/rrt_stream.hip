@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kStreamThreads) void rrt_stream_kernel(DevParams p_
 
         // 2. sample (rrt.rs:177-184)
         double q[D];
-        sample_state<D>(rng, p, dim, goal_c, q);
+        sample_state<D>(rng, p, dim, goal_c, q, p.goal_r[prob]);
 
         // 3. nearest neighbour (rrt.rs:187-196).  First a binary32 SCREEN over the shadow (coalesced SoA scan, 4 bytes
         //    per coordinate): smallest and second smallest squared distance.  If the runner-up is provably farther than
@@ -313,6 +313,8 @@ __global__ void f64_op_kernel(uint32_t op, const double* a, const double* b, con
         case 1: r = x / y; break;
         case 2: r = ceil(x); break;
         case 3: { double diff = y - x; double sc = diff * z; r = x + sc; } break;
+        case 5: { double sn, cs; ox_sincos(x, sn, cs); r = sn; } break;   // the disc goal sampler's sin / cos (ox_sincos.hpp)
+        case 6: { double sn, cs; ox_sincos(x, sn, cs); r = cs; } break;
         default: { double d = x - y; r = d * d; } break;
     }
     out[i] = r;

@@ -31,12 +31,16 @@ class RRT:
     for narrow-passage problems.  `solve(0)` is Timeout, as upstream."""
     _PLANNER = capi.PLANNER_RRT
 
-    def __init__(self, max_distance, goal_bias, problem_definition, max_nodes=10000, seed=0, problem_id=0, device=0):
+    def __init__(self, max_distance, goal_bias, problem_definition, max_nodes=10000, seed=0, problem_id=0, device=0,
+                 goal_sampler=capi.GOAL_SAMPLE_CENTRE):
+        """goal_sampler: what `goal.sample_goal()` draws on the device -- capi.GOAL_SAMPLE_CENTRE (the goal's `target`, as the
+        README's goal, no random draw) or capi.GOAL_SAMPLE_UNIFORM_DISC (uniform in the disc as the CircularGoal of
+        oxmpl-py/tests/test_rrt_rvss.py:19-25 and oxmpl/tests/rrt_rvss_tests.rs:55-66 samples it; 2-D spaces)"""
         if not isinstance(problem_definition, ProblemDefinition):
             raise TypeError("problem_definition must be a ProblemDefinition")
         self.max_distance, self.goal_bias = float(max_distance), float(goal_bias)
         self._pd = problem_definition
-        self._opts = dict(max_nodes=max_nodes, seed=seed, first_problem_id=problem_id, device=device)
+        self._opts = dict(max_nodes=max_nodes, seed=seed, first_problem_id=problem_id, device=device, goal_sampler=goal_sampler)
         self._batch = None
 
     def setup(self, validity_checker):

@@ -59,6 +59,21 @@ pub trait DeviceValidityChecker: StateValidityChecker<RealVectorState> {
 /// correctly but draw a different random stream than the CPU planner would.
 pub trait DeviceGoal: GoalSampleableRegion<RealVectorState> {
     fn ball(&self) -> (Vec<f64>, f64);
+    /// what `sample_goal` draws on the device (default: the centre, no random word -- README.md:160-162)
+    fn sampling(&self) -> GoalSampling {
+        GoalSampling::Centre
+    }
+}
+
+/// What `sample_goal` draws on the device (`oxhip_goal_sampler`).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum GoalSampling {
+    /// the ball's centre, no random word consumed (`README.md:160-162`)
+    Centre,
+    /// uniform in the disc, as the `CircularGoalRegion` of `oxmpl/tests/rrt_rvss_tests.rs:55-66` samples it:
+    /// `random_range(0.0..2.0 * PI)`, then `random::<f64>().sqrt()`; 2-D spaces.  The device evaluates cos / sin with its own
+    /// portable routine (within one ulp of libm): results are within 1e-6 relative of the CPU path, not bit-identical.
+    UniformDisc,
 }
 
 /// Deterministic knobs the reference does not have (its only stop is the wall clock, rrt.rs:172-174, and its RNG
@@ -288,6 +303,10 @@ impl<D: DeviceValidityChecker, G: DeviceGoal> Planner<RealVectorState, RealVecto
         cfg.first_problem_id = self.options.stream;
         cfg.device = self.options.device;
         cfg.space = ffi::OXHIP_SPACE_REAL_VECTOR;
+        cfg.goal_sampler = match problem_def.goal.sampling() {
+            GoalSampling::Centre => ffi::OXHIP_GOAL_SAMPLE_CENTRE,
+            GoalSampling::UniformDisc => ffi::OXHIP_GOAL_SAMPLE_UNIFORM_DISC,
+        };
         match self.planner {
             TreePlanner::Rrt => cfg.planner = ffi::OXHIP_PLANNER_RRT,
             TreePlanner::RrtConnect => cfg.planner = ffi::OXHIP_PLANNER_RRT_CONNECT,

@@ -183,7 +183,7 @@ FNV_BASIS = 0xCBF29CE484222325
 
 
 def rrt_solve(dim, bounds, max_distance, goal_bias, fraction, field, start, goal_c, goal_r,
-              seed, pid, max_iterations, max_nodes, stop_at_goal=True, freeze=False):
+              seed, pid, max_iterations, max_nodes, stop_at_goal=True, freeze=False, goal_sampler=None):
     rng = ChaCha12Rng(seed, pid)
     cap = max_nodes + 1
     tree = np.zeros((cap, dim), dtype=np.float64)
@@ -197,7 +197,7 @@ def rrt_solve(dim, bounds, max_distance, goal_bias, fraction, field, start, goal
         if (not freeze) and n >= max_nodes:
             break
         if random_bool(rng, goal_bias):
-            q_rand = list(goal_c)
+            q_rand = goal_sampler(rng) if goal_sampler is not None else list(goal_c)   # (make_golden_disc.py passes the disc sampler)
         else:
             q_rand = [random_range(rng, lo, hi) for lo, hi in bounds]
         acc = np.zeros(n)
