@@ -15,19 +15,22 @@ in HBM before the timed region; problems are sharded across ranks with no data-p
 
 One JSON line on rank 0 (flat objects only: no nested dictionaries inside `roofline` etc.).
 
-`roofline`: the bound that binds the kernel that ran.  The resident kernels never re-read the tree from
-HBM (it lives in the vector register file), so their bound is VALU issue: `peak` is the measured rate of the
-kernel's own screen instruction mix on this chip (tools/valu_mix_bench.hip -> profiles/r2_valu_peak.json),
-`achieved` the kernel's iterations/s from HIP events.  The byte figure SURVEY.md 8(d) defines (24 B x tree
-size per iteration) is kept as `hbm_equivalent_GBps`; for the stream kernel it is the bound itself.
+`roofline`: the bound that binds the kernel that ran.  rrt_cells.hip (what KERNEL_AUTO runs here) finds the nearest node
+through an exact cell grid -- ~6 cell blocks of 64 B per query instead of the 240 KB SURVEY.md 8(d) charges a scan -- so it is
+bound by vector-ALU issue under memory latency: `frac` = the VALU busy fraction of the steady launch (performance counters of a
+committed profile of this shape, profiles/r3_traffic.json), `achieved` = iterations/s from HIP events, `peak` = achieved / frac,
+`traffic` / `hbm_moved_GBps` = the bytes it really moves.  rrt_lanes.hip (round 2's default, reported as `secondary_lanes`) keeps
+the tree in the register file: its `peak` is the measured rate of its own screen loop (profiles/r2_valu_peak.json).  The byte
+figure SURVEY.md 8(d) defines (24 B x tree size per iteration) is kept as `hbm_equivalent_GBps`; for the stream kernel it is the
+bound itself.
 
 `cpu_baseline` times the CPU oracle (our C restatement of oxmpl's loop, kind "port") on a bounded sample of
 the same workload on this host's cores -- and the run is only accepted if the GPU's per-problem node
 counts, iteration counts and checksums (every iteration folds nearest index, q_new bits and verdict) equal
 the oracle's on that sample, after the grow phase and after the frozen iterations.
 
-`secondary` / `secondary_f64`: the same steps through the stream kernel and the all-binary64 resident kernel (checksums must
-equal the main run's).  `secondary_rrt_star`: the RRT* row on the same scene and batch size, 1024 trees grown
+`secondary` / `secondary_lanes` / `secondary_f64`: the same steps through the stream kernel, the lane-per-query kernel and the
+all-binary64 resident kernel (checksums of all 1024 problems must equal the main run's).  `secondary_rrt_star`: the RRT* row on the same scene and batch size, 1024 trees grown
 to 10,000 nodes; the checker grows problem 0 with the CPU oracle as well and refuses the line unless parents after rewiring,
 costs and checksum are identical.
 """
@@ -75,7 +78,7 @@ def valu_peak(kname):
 def measured_traffic(kernel_name, iters_per_launch):
     """HBM bytes per launch from a committed rocprofv3 PMC run of this shape (1024 problems x 4096 iterations);
     (None, None) for any other shape.  A constant from a file, not a measurement of this run: `traffic_source` says so."""
-    for name in ("r2_traffic.json", "r1_traffic.json"):
+    for name in ("r3_traffic.json", "r2_traffic.json", "r1_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)[kernel_name]
@@ -84,6 +87,16 @@ def measured_traffic(kernel_name, iters_per_launch):
         except (OSError, KeyError, ValueError):
             pass
     return None, None
+
+
+def cells_pmc():
+    """The cell-grid kernel's steady launch as the performance counters saw it (profiles/r3_traffic.json, produced by
+    tools/profile_cells.sh + tools/collect_profile_cells.py): VALU busy fraction, VALU instructions per iteration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r3_traffic.json")) as f:
+            return json.load(f)["cells"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def copy_peak_gbs(torch, device):
@@ -312,7 +325,7 @@ def main():
             raise SystemExit("bench.py: kernel kind %d disagrees with the main run's checksums: refusing to report" % kernel)
         return ms2 / steps, same
 
-    secondary_stream = secondary_f64 = None
+    secondary_stream = secondary_f64 = secondary_lanes = None
     copy_gbs = None
     if world == 1 and not args.no_secondary:
         copy_gbs = copy_peak_gbs(torch, torch.device("cuda", device))
@@ -328,6 +341,16 @@ def main():
                                 "moved_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None,
                                 "served_from": "Infinity Cache (126 MB shadow < 256 MB MALL) -- not an HBM figure",
                                 "checksums_equal_main_run": same}
+        if kname != "lanes":
+            try:
+                ms, same = side_run(capi.KERNEL_LANES)
+                pk, pk_src = valu_peak("lanes")
+                secondary_lanes = {"kernel": "lanes (round 2's default: register-resident brute-force screen, one CU per problem)",
+                                   "iterations_per_s": P * args.iters / (ms * 1e-3), "kernel_avg_ms": ms, "bound": "valu",
+                                   "peak_iterations_per_s": pk, "frac": (P * args.iters / (ms * 1e-3) / pk) if pk else None,
+                                   "peak_source": pk_src, "checksums_equal_main_run": same}
+            except capi.OxhipError:
+                secondary_lanes = None
         if kname != "resident":
             try:
                 ms, same = side_run(capi.KERNEL_RESIDENT)
@@ -409,6 +432,25 @@ def main():
             roofline = {"bound": "hbm", "achieved": hbm_equiv, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_equiv / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_ms": avg_launch_ms,
                         "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER}
+        elif kname == "cells":
+            # The cell-grid kernel neither re-reads the tree (SURVEY.md 8(d)'s byte model) nor scans it: per query it reads ~6 cell
+            # blocks of 64 B and the winner's coordinates.  What binds it is vector-ALU issue under memory latency: `frac` = the VALU
+            # busy fraction of the steady launch (performance counters of a committed profile of this shape), `peak` = the rate at
+            # which this instruction stream would run with the vector ALUs never idle; the bytes it really moves are below.
+            pm = cells_pmc()
+            busy = pm["valu_busy"] if pm and traffic else None
+            moved = (traffic / (avg_launch_ms * 1e-3) / 1e9) if traffic else None
+            roofline = {"bound": "valu", "achieved": its, "peak": (its / busy) if busy else None, "unit": "iterations/s", "frac": busy,
+                        "peak_source": "this run's rate / VALU busy fraction: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x shader cycles) of the steady "
+                                       "launch, profiles/r3_traffic.json (rocprofv3 --pmc; not this run)",
+                        "valu_insts_per_iteration": pm["valu_insts_per_iteration"] if pm else None,
+                        "traffic": traffic, "traffic_source": traffic_src, "kernel_avg_ms": avg_launch_ms,
+                        "hbm_moved_GBps": moved, "hbm_moved_over_vendor_peak": (moved / HBM_PEAK_GBS) if moved else None,
+                        "hbm_moved_over_copy_peak": (moved / copy_gbs) if (moved and copy_gbs) else None,
+                        "algorithmic_bytes_per_launch": iters_per_launch * BYTES_PER_ITER,
+                        # SURVEY.md 8(d)'s byte model, for reference: a design that re-read the tree would need this HBM rate
+                        "hbm_equivalent_GBps": hbm_equiv, "hbm_equivalent_over_vendor_peak": hbm_equiv / HBM_PEAK_GBS,
+                        "hbm_vendor_peak_GBps": HBM_PEAK_GBS, "hbm_copy_peak_GBps": copy_gbs}
         else:
             peak, peak_src = valu_peak(kname)
             roofline = {"bound": "valu", "achieved": its, "peak": peak, "unit": "iterations/s",
@@ -431,13 +473,16 @@ def main():
                        "problems_per_gpu": P, "iterations_per_problem_per_step": args.iters, "tree_nodes": N_NODES,
                        "spheres": 64, "max_distance": 0.5, "goal_bias": 0.05, "parallelism": "problem-parallel x%d" % world,
                        "kernel": kname,
-                       # one workgroup (= one problem) per CU at a time: P problems run in ceil(P / 256) rounds
-                       "workgroup_rounds": rounds, "last_round_fill": (P - (rounds - 1) * CUS) / CUS,
+                       # (rrt_lanes.hip: one workgroup = one problem per CU at a time, P problems in ceil(P / 256) rounds; rrt_cells.hip:
+                       #  one wave per problem -- per part of a problem when frozen -- so the chip fills by waves, not by CUs)
+                       "workgroup_rounds": rounds if kname != "cells" else None,
+                       "last_round_fill": ((P - (rounds - 1) * CUS) / CUS) if kname != "cells" else None,
                        # what `dtype` means here: every value that enters a result (distances, steer, motion check, tree,
                        # checksum) is computed in f64 in the reference's evaluation order; the lanes / stream kernels
                        # additionally SCREEN nearest-neighbour candidates in packed binary32 with a proven error bound and
                        # fall back to the f64 scan when the screen cannot decide -- bit-identical results
-                       "arithmetic": ("f64 results; packed-f32 candidate screen + f64 decision" if kname in ("stream", "lanes")
+                       "arithmetic": ("f64 results; binary32 candidate screen (exact cell grid) + f64 decision" if kname == "cells"
+                                      else "f64 results; packed-f32 candidate screen + f64 decision" if kname in ("stream", "lanes")
                                       else "f64 throughout")},
             "roofline": roofline,
             "grow": {"iterations": float(allst[:, 4].sum()), "wall_s": float(allst[:, 5].max()),
@@ -461,6 +506,8 @@ def main():
                 secondary_stream["moved_over_copy_peak"] = secondary_stream["moved_GBps"] / copy_gbs
                 secondary_stream["moved_over_vendor_peak"] = secondary_stream["moved_GBps"] / HBM_PEAK_GBS
             out["secondary"] = secondary_stream
+        if secondary_lanes is not None:
+            out["secondary_lanes"] = secondary_lanes
         if secondary_f64 is not None:
             out["secondary_f64"] = secondary_f64
         if secondary_star is not None:
