@@ -32,6 +32,7 @@ struct oxhip_rrt_batch {
     bool filt_dirty = true;
     DevBuf<CellBlock> cell_blk;     // rrt_cells.hip: cell blocks, flat lists of small trees, grid descriptors, accumulators of split frozen launches
     DevBuf<float> cell_flat;
+    DevBuf<double> cell_xyz;
     DevBuf<CellMeta> cell_meta;
     DevBuf<CellAcc> cell_acc;
     DevBuf<uint64_t> cell_part_pos;
@@ -198,7 +199,8 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         chk(b->parent_b.alloc((size_t)P * cap));
     }
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR) {
-        const bool geo_cells = cfg->kernel != OXHIP_KERNEL_LANES && cells_supported(dim, cap);
+        const bool geo_cells = cfg->kernel != OXHIP_KERNEL_LANES && cells_supported(dim, cap) &&
+                               !(cfg->kernel == OXHIP_KERNEL_AUTO && P <= 256u && lanes_supported(dim, cap));   // (small batches: see KERNEL_AUTO below)
         const bool geo_lanes = cfg->kernel != OXHIP_KERNEL_CELLS && lanes_supported(dim, cap);
         const bool can_wire = star_wire_supported(dim) && (geo_cells || geo_lanes);
         b->star_wired = cfg->kernel == OXHIP_KERNEL_LANES || cfg->kernel == OXHIP_KERNEL_CELLS || (cfg->kernel == OXHIP_KERNEL_AUTO && can_wire);
@@ -272,7 +274,14 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     uint32_t kind = cfg->kernel;
     if (cfg->planner != OXHIP_PLANNER_RRT) kind = b->star_wired ? (b->star_geo_cells ? OXHIP_KERNEL_CELLS : OXHIP_KERNEL_LANES) : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO)
-        kind = cells_supported(dim, cap) ? OXHIP_KERNEL_CELLS : lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
+    {
+        // rrt_cells.hip runs one WAVE per problem: a batch fills the chip from ~1,000 problems on (one wave per SIMD) and a growing
+        // tree takes ~12 ms to reach 10,000 nodes whatever the batch size; rrt_lanes.hip gives every problem a whole CU: 5.7 ms for
+        // the same tree, but only 256 problems at a time.  So small batches -- the one-problem Planner::solve of the trait surface
+        // above all -- run the latter (profiles/r3_single/), larger ones the former.
+        const bool small_batch = P <= 256u && lanes_supported(dim, cap);
+        kind = (cells_supported(dim, cap) && !small_batch) ? OXHIP_KERNEL_CELLS : lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
+    }
     if (kind == OXHIP_KERNEL_CELLS) {
         if (!cells_supported(dim, cap)) {
             oxhip_rrt_batch_destroy(b);
@@ -288,6 +297,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         dp.cells_split = split;
         hipError_t e2 = b->cell_blk.alloc((size_t)P * dp.cell_blocks);
         if (e2 == hipSuccess) e2 = b->cell_flat.alloc((size_t)P * 1024 * 4);
+        if (e2 == hipSuccess) e2 = b->cell_xyz.alloc((size_t)P * cap * 4);
         if (e2 == hipSuccess) e2 = b->cell_meta.alloc(P);
         if (e2 == hipSuccess) e2 = b->cell_acc.alloc(P);
         if (e2 == hipSuccess) e2 = b->cell_part_pos.alloc((size_t)P * 8);
@@ -298,7 +308,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             oxhip_rrt_batch_destroy(b);
             return fail(OXHIP_ERR_HIP, msg);
         }
-        dp.cell_blk = b->cell_blk.p; dp.cell_flat = b->cell_flat.p; dp.cell_meta = b->cell_meta.p;
+        dp.cell_blk = b->cell_blk.p; dp.cell_flat = b->cell_flat.p; dp.cell_xyz = b->cell_xyz.p; dp.cell_meta = b->cell_meta.p;
         dp.cell_acc = b->cell_acc.p; dp.cell_part_pos = b->cell_part_pos.p;
     }
     if (kind == OXHIP_KERNEL_LANES && !lanes_supported(dim, cap)) {

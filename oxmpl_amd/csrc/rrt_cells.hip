@@ -46,6 +46,7 @@ constexpr int kMaxShell = 6;                         // the cooperative search g
 
 typedef float cfloat4 __attribute__((ext_vector_type(4)));
 typedef uint32_t cuint4 __attribute__((ext_vector_type(4)));
+typedef double cdouble4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kBlkEntries = 7;
 
 struct CellGrid {   // wave-uniform
@@ -173,6 +174,7 @@ __device__ __forceinline__ void cells_build(const DevParams& p, uint32_t prob, u
     const uint8_t* skip = p.skip + (size_t)prob * cap;
     CellBlock* blk = p.cell_blk + (size_t)prob * p.cell_blocks;
     cfloat4* flat = reinterpret_cast<cfloat4*>(p.cell_flat) + (size_t)prob * kBruteMax;
+    cdouble4* xyz = reinterpret_cast<cdouble4*>(p.cell_xyz) + (size_t)prob * cap;
     double lo[DIM], hi[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) {
@@ -230,6 +232,7 @@ __device__ __forceinline__ void cells_build(const DevParams& p, uint32_t prob, u
         double err;
         uint64_t entry;
         const uint32_t cell = cell_place<DIM>(g, x, i, entry, tf, err);
+        if (in) xyz[i] = cdouble4{x[0], x[1], DIM >= 3 ? x[DIM - 1] : 0.0, 0.0};
         const bool keep = in && skip[in ? i : 0u] == 0;   // a duplicate of a lower-index node can never win (strict '<', rrt.rs:192)
         if (keep) derr = fmax(derr, err);
         if (g.level == 0) {
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
     uint8_t* skip = p.skip + (size_t)prob * cap;
     CellBlock* blk = p.cell_blk + (size_t)prob * p.cell_blocks;
     cfloat4* flat = reinterpret_cast<cfloat4*>(p.cell_flat) + (size_t)prob * kBruteMax;
+    cdouble4* xyz = reinterpret_cast<cdouble4*>(p.cell_xyz) + (size_t)prob * cap;
     double goal_c[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
@@ -599,7 +603,6 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
 #pragma unroll
         for (int k = 0; k < D; ++k) q[k] = sh->q[k][slot];
         const uint64_t pos_after_l = sh->pos_after[slot];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's own earlier stores (tree, grid nodes) have landed
 
         // ---- nearest neighbour (rrt.rs:187-196): a binary32 screen over the cells around the query names one candidate
         Top2 t2{__builtin_inff(), __builtin_inff(), kNoNode};
@@ -614,6 +617,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         const uint32_t gmax = grid.G[0] > grid.G[1] ? (grid.G[0] > grid.G[2] ? grid.G[0] : grid.G[2]) : (grid.G[1] > grid.G[2] ? grid.G[1] : grid.G[2]);
         const double A = sqrt((double)D) * (grid.delta_node + (double)(gmax + 8u) * 0x1p-23) * 1.01 + 1e-30;
         int verdict;   // 0 proven, 2 ambiguous (whole-tree path)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's own earlier stores (tree, cell blocks) have landed: the loads below may read them
         bool from_memo = act && memo_n == n;
 #pragma unroll
         for (int k = 0; k < D; ++k) from_memo = from_memo && __double_as_longlong(q[k]) == __double_as_longlong(memo_q[k]);
@@ -774,8 +778,9 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         double q_near[D];
         {
             const uint32_t ni = nearest == kNoNode ? 0u : nearest;
+            const cdouble4 c4 = xyz[ni];   // (the node-major copy: one 32-byte access instead of D cache lines)
 #pragma unroll
-            for (int k = 0; k < D; ++k) q_near[k] = tree[(size_t)k * cap + ni];
+            for (int k = 0; k < D; ++k) q_near[k] = c4[k];
         }
         double g = nearest == kNoNode ? __builtin_inf() : dist2<D>(q_near, q, DIM);
         // the screen's own claim, checked on the binary64 value (turns a corrupted record into an unproven lane)
@@ -784,8 +789,9 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         if (from_memo) {   // the whole-tree path's last answer, for this very query on this very tree
             nearest = memo_idx;
             g = memo_g;
+            const cdouble4 m4 = xyz[memo_idx];
 #pragma unroll
-            for (int k = 0; k < D; ++k) q_near[k] = tree[(size_t)k * cap + memo_idx];
+            for (int k = 0; k < D; ++k) q_near[k] = m4[k];
             clear = true;
         }
         if (STAMP) n_memo += (uint64_t)__popcll(__ballot(from_memo));
@@ -977,6 +983,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
                     // '<' of rrt.rs:192 can never prefer -- its cell's list
 #pragma unroll
                     for (int k = 0; k < D; ++k) tree[(size_t)k * cap + idx] = qn[k];
+                    xyz[idx] = cdouble4{qn[0], qn[1], D >= 3 ? qn[D - 1] : 0.0, 0.0};
                     parent[idx] = (int32_t)nearest;
                     skip[idx] = dup ? 1 : 0;
                 }
@@ -1144,6 +1151,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
                     if (lane == 0) {
 #pragma unroll
                         for (int k = 0; k < D; ++k) tree[(size_t)k * cap + i] = qn1[k];
+                        xyz[i] = cdouble4{qn1[0], qn1[1], D >= 3 ? qn1[D - 1] : 0.0, 0.0};
                         parent[i] = (int32_t)nearest1;
                         skip[i] = dup1 ? 1 : 0;
                         if (grid.level == 0 && i < kBruteMax)

@@ -78,7 +78,7 @@ def test_rrt_with_the_disc_goal_sampler(scene, goal_bias, kernel):
     g.close()
 
 
-@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANES, capi.KERNEL_STREAM], ids=["auto", "lanes", "one_kernel"])
+@pytest.mark.parametrize("kernel", [capi.KERNEL_CELLS, capi.KERNEL_LANES, capi.KERNEL_STREAM], ids=["decoupled_cells", "decoupled_lanes", "one_kernel"])
 def test_rrt_star_with_the_disc_goal_sampler(kernel):
     sc = dict(scenarios.wall(), goal_bias=0.2)
     g = scenarios.make_batch(sc, 4, 1500, False, 21, 5, 0, kernel, capi.PLANNER_RRT_STAR, 0.8, goal_sampler=capi.GOAL_SAMPLE_UNIFORM_DISC)

@@ -1,7 +1,7 @@
 """GPU parity tests of RRT* (planner kind 2) through the C ABI against the CPU oracle (orc_rrts_*) and the golden
 fixtures: node count, iteration count, checksum (iteration polynomial over nearest / q_new / verdict + wiring polynomial over
 chosen parent / cost bits / rewired count and index sum), tree bits, parents after rewiring, costs, path.
-Every test runs on both designs: "decoupled" (KERNEL_AUTO: geometry by rrt_lanes.hip, wiring by rrt_star_wire.hip) and
+Every test runs on the designs "decoupled" (geometry by rrt_cells.hip or rrt_lanes.hip, wiring by rrt_star_wire.hip) and
 "one_kernel" (KERNEL_STREAM: rrt_star.hip).  PARITY UNPINNED against oxmpl itself."""
 import json
 import os
@@ -22,8 +22,9 @@ DESIGN = {"kernel": capi.KERNEL_AUTO}
 
 @pytest.fixture(autouse=True, params=["decoupled", "decoupled_lanes", "one_kernel"])
 def star_design(request):
-    # decoupled: KERNEL_AUTO = geometry by rrt_cells.hip (R^2 / R^3) + rrt_star_wire.hip; decoupled_lanes: geometry by rrt_lanes.hip
-    DESIGN["kernel"] = {"decoupled": capi.KERNEL_AUTO, "decoupled_lanes": capi.KERNEL_LANES, "one_kernel": capi.KERNEL_STREAM}[request.param]
+    # decoupled: geometry by rrt_cells.hip (what KERNEL_AUTO runs for batches of more than 256 problems in R^2 / R^3) + rrt_star_wire.hip;
+    # decoupled_lanes: geometry by rrt_lanes.hip (KERNEL_AUTO's choice for small batches and R^4 .. R^6)
+    DESIGN["kernel"] = {"decoupled": capi.KERNEL_CELLS, "decoupled_lanes": capi.KERNEL_LANES, "one_kernel": capi.KERNEL_STREAM}[request.param]
     yield request.param
     DESIGN["kernel"] = capi.KERNEL_AUTO
 
