@@ -308,6 +308,11 @@ typedef struct oxhip_prm_config {
                                            (so that a space with no valid state still returns) */
     uint64_t seed;                      /* ChaCha12 key = LE(seed)||0^24 */
     uint64_t stream;                    /* ChaCha12 stream id */
+    uint32_t knn_k;                     /* 0: the reference's rule -- a new milestone connects to every earlier one within connection_radius
+                                           (prm.rs:131-138).  k > 0: the k-nearest variant (BASELINE.json configs[4]: "all-pairs k-NN"): it connects
+                                           to its k nearest earlier milestones, ordered by (distance, index), visited in ascending index order;
+                                           check_motion and everything else as prm.rs.  The query's start connections keep the radius rule */
+    uint32_t reserved;                  /* 0 */
 } oxhip_prm_config;
 
 typedef struct oxhip_prm oxhip_prm;
@@ -342,6 +347,9 @@ int32_t oxhip_prm_get_query_sets(oxhip_prm* prm, uint32_t* start_connections, ui
  * replayed because rand's range sampler rejected a draw */
 int32_t oxhip_prm_last_timing(oxhip_prm* prm, double* phase_ms /*[6]*/, uint64_t* n_candidates,
                               uint32_t* redraw_batches);
+/* k-nearest variant, last construct_roadmap: rows whose candidate radius held fewer than k earlier milestones and that were
+ * searched exactly instead (diagnostic: results do not depend on it) */
+int32_t oxhip_prm_knn_exact_rows(oxhip_prm* prm, uint32_t* rows);
 
 #ifdef __cplusplus
 }

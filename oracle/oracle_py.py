@@ -163,6 +163,7 @@ def lib():
         L.orc_prm_setup.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
         L.orc_prm_set_problem.argtypes = [C.c_void_p, _dp, _dp, C.c_double]
         L.orc_prm_construct_roadmap.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+        L.orc_prm_set_knn.argtypes = [C.c_void_p, C.c_uint32]
         L.orc_prm_num_milestones.argtypes = [C.c_void_p]
         L.orc_prm_num_milestones.restype = C.c_uint32
         for name in ("orc_prm_num_edge_entries", "orc_prm_num_samples"):
@@ -435,6 +436,10 @@ class OraclePRM:
         s, ps = _d(start)
         g, pg = _d(goal_centre)
         return lib().orc_prm_set_problem(self._h, ps, pg, goal_radius)
+
+    def set_knn(self, k):
+        """k > 0: the k-nearest variant (every new milestone connects to its k nearest earlier ones); 0: the reference's radius rule"""
+        return lib().orc_prm_set_knn(self._h, int(k))
 
     def construct_roadmap(self, max_milestones, max_samples=2 ** 62):
         return lib().orc_prm_construct_roadmap(self._h, max_milestones, max_samples)

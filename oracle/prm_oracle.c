@@ -27,6 +27,7 @@ struct orc_prm {
     double bounds[2 * ORC_MAX_DIM];
     double timeout;            /* PRM::timeout (prm.rs:50), seconds of roadmap construction */
     double connection_radius;  /* prm.rs:52 */
+    uint32_t knn_k;            /* 0: the reference's radius connection; k > 0: the k-nearest variant (BASELINE.json configs[4]) */
     double lvs_fraction;
     uint64_t seed, stream;
     orc_rng rng;
@@ -176,6 +177,9 @@ int orc_prm_construct_roadmap(orc_prm* p, uint32_t max_milestones, uint64_t max_
     double q_rand[ORC_MAX_DIM];
     uint32_t* to_update = NULL;
     uint32_t cap_update = 0;
+    double* knn_d = NULL;
+    uint32_t* knn_i = NULL;
+    uint32_t knn_cap = 0;
     for (;;) {
         if (now_s() - start_time > p->timeout) break;                        /* prm.rs:118-120 */
         if (p->n >= max_milestones || p->n_samples >= max_samples) break;    /* build-defined caps */
@@ -185,7 +189,46 @@ int orc_prm_construct_roadmap(orc_prm* p, uint32_t max_milestones, uint64_t max_
         if (!is_valid(p, q_rand)) continue;                                  /* prm.rs:123 */
         prm_node new_node = {dup_vec(q_rand, p->dim), NULL, 0, 0};
         uint32_t n_update = 0;
-        for (uint32_t i = 0; i < p->n; ++i) {                                /* prm.rs:131-138 */
+        /* k-nearest variant (an extension: the reference connects by radius): the candidates are the k earlier milestones
+         * nearest to the new one, by (distance, index) -- strict order, the lower index first among equal distances --, visited
+         * in ascending index order like the reference's loop, so every `edges` vector still ends up ascending (prm.rs:143-145). */
+        if (p->knn_k > 0 && p->n > 0) {
+            const uint32_t k = p->knn_k < p->n ? p->knn_k : p->n;
+            if (k > knn_cap) {
+                knn_cap = k;
+                knn_d = (double*)realloc(knn_d, sizeof(double) * knn_cap);
+                knn_i = (uint32_t*)realloc(knn_i, sizeof(uint32_t) * knn_cap);
+            }
+            uint32_t m = 0;   /* the k best so far, sorted by (distance, index) ascending */
+            for (uint32_t i = 0; i < p->n; ++i) {
+                const double dist = orc_distance(q_rand, p->roadmap[i].values, p->dim);
+                if (m == k && !(dist < knn_d[k - 1])) continue;   /* (equal distance, higher index: not better) */
+                uint32_t pos = m < k ? m : k - 1;
+                while (pos > 0 && dist < knn_d[pos - 1]) { knn_d[pos] = knn_d[pos - 1]; knn_i[pos] = knn_i[pos - 1]; --pos; }
+                knn_d[pos] = dist;
+                knn_i[pos] = i;
+                if (m < k) ++m;
+            }
+            /* ascending index order */
+            for (uint32_t a = 1; a < m; ++a) {
+                uint32_t vi = knn_i[a];
+                uint32_t b = a;
+                while (b > 0 && knn_i[b - 1] > vi) { knn_i[b] = knn_i[b - 1]; --b; }
+                knn_i[b] = vi;
+            }
+            for (uint32_t a = 0; a < m; ++a) {
+                const uint32_t i = knn_i[a];
+                if (check_motion(p, q_rand, p->roadmap[i].values)) {
+                    push_edge(&new_node, i);
+                    if (n_update == cap_update) {
+                        cap_update = cap_update ? cap_update * 2 : 16;
+                        to_update = (uint32_t*)realloc(to_update, sizeof(uint32_t) * cap_update);
+                    }
+                    to_update[n_update++] = i;
+                }
+            }
+        }
+        for (uint32_t i = 0; p->knn_k == 0 && i < p->n; ++i) {              /* prm.rs:131-138 */
             const double* other = p->roadmap[i].values;
             double dist = orc_distance(q_rand, other, p->dim);
             if (dist < p->connection_radius && check_motion(p, q_rand, other)) {
@@ -206,7 +249,17 @@ int orc_prm_construct_roadmap(orc_prm* p, uint32_t max_milestones, uint64_t max_
         for (uint32_t u = 0; u < n_update; ++u) push_edge(&p->roadmap[to_update[u]], new_idx); /* prm.rs:143-145 */
     }
     free(to_update);
+    free(knn_d);
+    free(knn_i);
     return ORC_SOLVED;
+}
+
+/* k > 0: connect every new milestone to its k nearest earlier ones (by (distance, index)) instead of to every earlier one within
+ * the connection radius; 0: the reference's rule.  The query (start connections) keeps the radius rule of prm.rs:249-256. */
+int orc_prm_set_knn(orc_prm* p, uint32_t k) {
+    if (!p) return ORC_BAD_ARG;
+    p->knn_k = k;
+    return 0;
 }
 
 uint32_t orc_prm_num_milestones(const orc_prm* p) { return p->n; }

@@ -41,6 +41,9 @@ int orc_prm_setup(orc_prm* p, const double* start, const double* goal_centre, do
 /* set_problem_definition (prm.rs:88-90): new start / goal, roadmap kept */
 int orc_prm_set_problem(orc_prm* p, const double* start, const double* goal_centre, double goal_radius);
 /* construct_roadmap (prm.rs:96-154) */
+/* k-nearest variant (BASELINE.json configs[4] says "all-pairs k-NN"; the reference itself connects by radius, prm.rs:131-138):
+ * k > 0 connects every new milestone to its k nearest earlier ones by (distance, index); 0 = the reference's rule */
+int orc_prm_set_knn(orc_prm* p, uint32_t k);
 int orc_prm_construct_roadmap(orc_prm* p, uint32_t max_milestones, uint64_t max_samples);
 uint32_t orc_prm_num_milestones(const orc_prm* p);
 uint64_t orc_prm_num_edge_entries(const orc_prm* p); /* sum over nodes of edges.len() = 2 x undirected edges */

@@ -41,7 +41,7 @@ EXPORTS = [
     "oxhip_f64_op_batch", "oxhip_se2_op_batch", "oxhip_rng_u64_batch",
     "oxhip_prm_create", "oxhip_prm_destroy", "oxhip_prm_set_spheres", "oxhip_prm_set_boxes", "oxhip_prm_setup",
     "oxhip_prm_set_problem", "oxhip_prm_construct_roadmap", "oxhip_prm_get_sizes", "oxhip_prm_get_roadmap",
-    "oxhip_prm_solve", "oxhip_prm_get_query_sets", "oxhip_prm_last_timing",
+    "oxhip_prm_solve", "oxhip_prm_get_query_sets", "oxhip_prm_last_timing", "oxhip_prm_knn_exact_rows",
 ]
 
 
@@ -62,7 +62,7 @@ class PrmConfig(C.Structure):
         ("struct_size", C.c_uint32), ("dim", C.c_uint32), ("bounds", C.c_double * (2 * MAX_DIM)),
         ("timeout", C.c_double), ("connection_radius", C.c_double), ("lvs_fraction", C.c_double),
         ("max_milestones", C.c_uint32), ("device", C.c_int32), ("max_samples", C.c_uint64),
-        ("seed", C.c_uint64), ("stream", C.c_uint64),
+        ("seed", C.c_uint64), ("stream", C.c_uint64), ("knn_k", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -144,6 +144,7 @@ def lib():
         L.oxhip_prm_solve.argtypes = [C.c_void_p, C.c_double, _dp, C.c_uint32, _u32p]
         L.oxhip_prm_get_query_sets.argtypes = [C.c_void_p, _u32p, C.c_uint32, _u32p, _u32p, C.c_uint32, _u32p]
         L.oxhip_prm_last_timing.argtypes = [C.c_void_p, _dp, _u64p, _u32p]
+        L.oxhip_prm_knn_exact_rows.argtypes = [C.c_void_p, _u32p]
         for name in EXPORTS:
             if name not in ("oxhip_status_string", "oxhip_last_error_string"):
                 getattr(L, name).restype = C.c_int32
@@ -389,7 +390,7 @@ class PRMRoadmap:
     """oxmpl's PRM (prm.rs) on one GPU: roadmap construction and queries.  Thin wrapper of oxhip_prm_*."""
 
     def __init__(self, dim, bounds, connection_radius, max_milestones, timeout=0.0, lvs_fraction=0.05,
-                 max_samples=0, seed=0, stream=0, device=0):
+                 max_samples=0, seed=0, stream=0, device=0, knn_k=0):
         cfg = PrmConfig()
         cfg.struct_size = C.sizeof(PrmConfig)
         cfg.dim = dim
@@ -401,6 +402,7 @@ class PRMRoadmap:
         cfg.timeout, cfg.connection_radius, cfg.lvs_fraction = timeout, connection_radius, lvs_fraction
         cfg.max_milestones, cfg.device, cfg.max_samples = max_milestones, device, max_samples
         cfg.seed, cfg.stream = seed, stream
+        cfg.knn_k = knn_k   # 0: radius connection (the reference); k > 0: connect to the k nearest earlier milestones
         self.dim = dim
         self._h = C.c_void_p()
         _check(lib().oxhip_prm_create(C.byref(cfg), C.byref(self._h)))
@@ -469,6 +471,12 @@ class PRMRoadmap:
         _check(lib().oxhip_prm_get_query_sets(self._h, _p(sc, _u32p), ns.value, C.byref(ns), _p(gi, _u32p), ng.value,
                                               C.byref(ng)))
         return sc[:ns.value], gi[:ng.value]
+
+    def knn_exact_rows(self):
+        """k-nearest variant: rows of the last construct_roadmap that were searched exactly (their candidate radius fell short)"""
+        r = C.c_uint32()
+        _check(lib().oxhip_prm_knn_exact_rows(self._h, C.byref(r)))
+        return r.value
 
     def last_timing(self):
         """dict(phase_ms=[sample, pairs, edges, sort+csr, query, bfs], candidates, redraw_batches)"""

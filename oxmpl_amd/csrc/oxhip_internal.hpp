@@ -100,7 +100,17 @@ struct PrmQuery {
 void launch_prm_sample(const DevParams& p, const PrmArgs& a, hipStream_t s);
 // speculative parallel round: draws, scans, compacts; the host commits sp.result when no draw was rejected
 void launch_prm_sample_spec(const DevParams& p, const PrmArgs& a, const PrmSpec& sp, uint32_t n0, hipStream_t s);
-void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_t j1, double thr, hipStream_t s);
+// thr_row / thr32_row (optional, [cap]): a threshold per row j instead of `thr` (the k-nearest variant's candidate search)
+void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_t j1, double thr, hipStream_t s, const double* thr_row = nullptr,
+                      const float* thr32_row = nullptr);
+float prm_screen_threshold(const DevParams& p, double thr);   // the binary32 screen's threshold for a binary64 d2 threshold
+// k-nearest variant: candidates -> sortable keys; sorted keys -> each row's k nearest (`sel`, counters[0] pairs; rows whose radius held
+// too few in failed_rows, counters[1] of them); the exact search for those rows
+void launch_prm_knn_keys(const PrmArgs& a, uint32_t n_cand, uint64_t* keys, hipStream_t s);
+void launch_prm_knn_select(const DevParams& p, const PrmArgs& a, const uint64_t* sorted, double* dist, uint32_t n_sorted, uint32_t j0, uint32_t j1,
+                           uint32_t k, uint2* sel, uint32_t* counters, uint32_t* failed_rows, hipStream_t s);
+void launch_prm_knn_brute(const DevParams& p, const PrmArgs& a, const uint32_t* failed_rows, uint32_t n_failed, uint32_t k, uint2* sel,
+                          uint32_t* counters, hipStream_t s);
 void launch_prm_edges(const DevParams& p, const PrmArgs& a, uint32_t n_cand, hipStream_t s);
 // rocPRIM radix sort of the directed keys; tmp == nullptr queries tmp_bytes
 hipError_t prm_sort_keys(void* tmp, size_t& tmp_bytes, uint64_t* in, uint64_t* out, uint32_t n_keys, uint32_t cap,

@@ -28,6 +28,13 @@ struct oxhip_prm {
     double maxabs = 1.0;      // largest |coordinate| of bounds and sphere centres (midpoint filter margin)
     DevBuf<PrmState> state;
     DevBuf<uint2> cand;
+    // k-nearest variant: per-row candidate radii, the sorted candidates and their distances, the selected pairs
+    DevBuf<double> knn_thr, knn_dist;
+    DevBuf<float> knn_thr32;
+    DevBuf<uint64_t> knn_keys, knn_sorted;
+    DevBuf<uint2> knn_sel;
+    DevBuf<uint32_t> knn_counters, knn_failed;
+    uint32_t knn_failed_rows = 0;   // rows of the last construct_roadmap that needed the exact search
     DevBuf<uint64_t> keys, keys_sorted;
     DevBuf<uint8_t> sort_tmp;
     uint32_t n_keys = 0;       // directed edge entries of the constructed roadmap
@@ -299,6 +306,7 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
     const uint64_t max_samples = h->cfg.max_samples ? h->cfg.max_samples : 4096ull * n_max + (1ull << 22);
     for (double& t : h->t_ms) t = 0.0;
     h->n_candidates = 0;
+    h->knn_failed_rows = 0;
     PrmState st{};
     OX_TRY(write_state(h, st));
     h->valid_rate = 1.0;
@@ -315,17 +323,43 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
         h->t_ms[0] += elapsed_ms(h->ev[0], h->ev[1]);
         const uint32_t n_now = st.n_milestones;
         // ---- 2. pairs (j in [n_done, n_now), i < j) within the connection radius
-        if (n_now > n_done && n_now >= 2 && h->thr_conn >= 0.0) {
+        if (n_now > n_done && n_now >= 2 && (h->thr_conn >= 0.0 || h->cfg.knn_k)) {
             if (h->cand.n == 0) {
                 HIP_TRY(h->cand.alloc(std::min<size_t>(std::max<size_t>(1u << 20, (size_t)64 * n_max), (size_t)1 << 28)));
                 h->args.cand = h->cand.p;
                 h->args.cand_cap = (uint32_t)h->cand.n;
             }
+            const uint32_t knn_k = h->cfg.knn_k;
+            if (knn_k) {
+                // k-nearest variant: row j searches a radius expected to hold ~6 k earlier milestones -- the milestones are uniform
+                // over the valid part of the box (fraction n / n_samples of its volume V): count(r) ~ j c_D r^D / (V f) -- so that its
+                // k nearest are almost surely among the hits; a row that falls short gets the exact search afterwards
+                const uint32_t dim = h->cfg.dim;
+                double vol = 1.0;
+                for (uint32_t k2 = 0; k2 < dim; ++k2) vol *= h->cfg.bounds[2 * k2 + 1] - h->cfg.bounds[2 * k2];
+                const double frac = st.n_samples ? std::fmin(1.0, (double)n_now / (double)st.n_samples) : 1.0;
+                const double c_d = std::pow(3.14159265358979323846, 0.5 * dim) / std::tgamma(0.5 * dim + 1.0);
+                const double want = 6.0 * knn_k;
+                std::vector<double> thr(h->args.cap, std::numeric_limits<double>::infinity());
+                std::vector<float> thr32(h->args.cap, std::numeric_limits<float>::infinity());
+                for (uint32_t j = n_done; j < n_now; ++j) {
+                    if ((double)j <= want) continue;   // few earlier milestones: all of them are candidates
+                    const double rd = want * vol * frac / (c_d * (double)j);
+                    const double r = std::pow(rd, 1.0 / dim);
+                    thr[j] = r * r;
+                    thr32[j] = prm_screen_threshold(h->dp, thr[j]);
+                }
+                if (h->knn_thr.n < h->args.cap) { HIP_TRY(h->knn_thr.alloc(h->args.cap)); HIP_TRY(h->knn_thr32.alloc(h->args.cap)); }
+                HIP_TRY(hipMemcpyAsync(h->knn_thr.p, thr.data(), thr.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(hipMemcpyAsync(h->knn_thr32.p, thr32.data(), thr32.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+            }
             for (;;) {
                 st.n_cand = 0;
                 OX_TRY(write_state(h, st));
                 HIP_TRY(hipEventRecord(h->ev[2], h->stream));
-                launch_prm_pairs(h->dp, h->args, n_done, n_now, h->thr_conn, h->stream);
+                if (knn_k) launch_prm_pairs(h->dp, h->args, n_done, n_now, std::numeric_limits<double>::infinity(), h->stream, h->knn_thr.p, h->knn_thr32.p);
+                else launch_prm_pairs(h->dp, h->args, n_done, n_now, h->thr_conn, h->stream);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(h->ev[3], h->stream));
                 PrmState s2{};
@@ -340,6 +374,44 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
                 h->args.cand_cap = (uint32_t)st.n_cand;
             }
             h->n_candidates += st.n_cand;
+            uint2* const cand_all = h->args.cand;
+            if (knn_k) {
+                // ---- 2b. each row's k nearest among its candidates (sorted by (j, i)); the exact search for rows that fell short
+                const uint32_t nc = (uint32_t)st.n_cand, rows = n_now - n_done;
+                if (h->knn_keys.n < nc + 1) {
+                    HIP_TRY(h->knn_keys.alloc(nc + 1)); HIP_TRY(h->knn_sorted.alloc(nc + 1)); HIP_TRY(h->knn_dist.alloc(nc + 1));
+                }
+                if (h->knn_sel.n < (size_t)rows * knn_k) HIP_TRY(h->knn_sel.alloc((size_t)rows * knn_k));
+                if (h->knn_failed.n < rows) HIP_TRY(h->knn_failed.alloc(rows));
+                if (h->knn_counters.n < 2) HIP_TRY(h->knn_counters.alloc(2));
+                size_t tb = 0;
+                if (nc) {
+                    HIP_TRY(prm_sort_keys(nullptr, tb, h->knn_keys.p, h->knn_sorted.p, nc, h->args.cap, h->stream));
+                    if (h->sort_tmp.n < tb) HIP_TRY(h->sort_tmp.alloc(tb));
+                }
+                HIP_TRY(hipEventRecord(h->ev[2], h->stream));
+                HIP_TRY(hipMemsetAsync(h->knn_counters.p, 0, 2 * sizeof(uint32_t), h->stream));
+                launch_prm_knn_keys(h->args, nc, h->knn_keys.p, h->stream);
+                if (nc) HIP_TRY(prm_sort_keys(h->sort_tmp.p, tb, h->knn_keys.p, h->knn_sorted.p, nc, h->args.cap, h->stream));
+                launch_prm_knn_select(h->dp, h->args, h->knn_sorted.p, h->knn_dist.p, nc, n_done, n_now, knn_k, h->knn_sel.p, h->knn_counters.p,
+                                      h->knn_failed.p, h->stream);
+                HIP_TRY(hipGetLastError());
+                uint32_t cnt[2] = {0, 0};
+                HIP_TRY(hipMemcpyAsync(cnt, h->knn_counters.p, sizeof cnt, hipMemcpyDeviceToHost, h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                if (cnt[1]) {
+                    launch_prm_knn_brute(h->dp, h->args, h->knn_failed.p, cnt[1], knn_k, h->knn_sel.p, h->knn_counters.p, h->stream);
+                    HIP_TRY(hipGetLastError());
+                    HIP_TRY(hipMemcpyAsync(cnt, h->knn_counters.p, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+                    HIP_TRY(hipStreamSynchronize(h->stream));
+                    h->knn_failed_rows += cnt[1];
+                }
+                HIP_TRY(hipEventRecord(h->ev[3], h->stream));
+                HIP_TRY(hipStreamSynchronize(h->stream));
+                h->t_ms[1] += elapsed_ms(h->ev[2], h->ev[3]);
+                st.n_cand = cnt[0];
+                h->args.cand = h->knn_sel.p;   // the edge kernel checks the selected pairs
+            }
             // ---- 3. check_motion per candidate; keys grow by at most 2 per candidate
             const uint64_t need = (uint64_t)st.n_keys + 2ull * st.n_cand;
             if (need > 0xFFFFFFFFull) return fail(OXHIP_ERR_CAPACITY, "more than 2^32 directed edges");
@@ -360,6 +432,7 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
             HIP_TRY(hipEventRecord(h->ev[3], h->stream));
             OX_TRY(read_state(h, st));
             h->t_ms[2] += elapsed_ms(h->ev[2], h->ev[3]);
+            h->args.cand = cand_all;
         }
         n_done = n_now;
         if (n_now < target) break;                       // max_samples exhausted
@@ -393,6 +466,12 @@ int32_t oxhip_prm_construct_roadmap(oxhip_prm* h) {
     h->n = n;
     h->n_samples = st.n_samples;
     h->redraw_batches = st.redraw_batches;
+    return OXHIP_OK;
+}
+
+int32_t oxhip_prm_knn_exact_rows(oxhip_prm* h, uint32_t* rows) {
+    if (!h || !rows) return fail(OXHIP_ERR_BAD_ARG, "null argument");
+    *rows = h->knn_failed_rows;
     return OXHIP_OK;
 }
 

@@ -337,7 +337,7 @@ __device__ __forceinline__ void stage_flush(const PrmArgs& a, PairStage& st, uin
 template <int DIM, bool DIAG>
 __device__ __forceinline__ void pairs_one_i(const PrmArgs& a, PairStage& st, uint32_t lane, const double (&cj)[kPairR][DIM],
                                             const pair_f32x2 (&cj32)[kPairR / 2][DIM], const uint32_t (&jr)[kPairR], const float (&ci)[DIM],
-                                            uint32_t i, double thr, float thr32, const double* __restrict__ ms) {
+                                            uint32_t i, const double (&thr)[kPairR], const float (&thr32)[kPairR], const double* __restrict__ ms) {
     // binary32 SCREEN of distance(q_rand, other)^2 for the thread's two milestones at once (packed: v_pk_add / v_pk_fma):
     // a pair whose screened value exceeds thr32 cannot pass the reference's test (screen_threshold, rrt_device.hpp) ...
     static_assert(kPairR % 2 == 0, "the milestones of a thread share packed registers two by two");
@@ -359,7 +359,7 @@ __device__ __forceinline__ void pairs_one_i(const PrmArgs& a, PairStage& st, uin
     bool any = false;
 #pragma unroll
     for (int r = 0; r < kPairR; ++r) {
-        h[r] = !(s[r / 2][r % 2] > thr32);   // "cannot be excluded": a NaN (inf - inf when the screen is switched off) passes
+        h[r] = !(s[r / 2][r % 2] > thr32[r]);   // "cannot be excluded": a NaN (inf - inf when the screen is switched off) passes
         if (DIAG) h[r] = h[r] && i < jr[r];
         any = any || h[r];
     }
@@ -380,7 +380,7 @@ __device__ __forceinline__ void pairs_one_i(const PrmArgs& a, PairStage& st, uin
                     d = d * d;
                     acc = acc + d;
                 }
-                h[r] = acc <= thr;
+                h[r] = acc <= thr[r];
             }
         }
 #pragma unroll
@@ -399,7 +399,7 @@ template <int DIM, bool DIAG>
 __device__ __forceinline__ void pairs_range(const PrmArgs& a, PairStage& st, uint32_t lane, const double (&cj)[kPairR][DIM],
                                             const pair_f32x2 (&cj32)[kPairR / 2][DIM], const uint32_t (&jr)[kPairR],
                                             const double* __restrict__ ms, const float* __restrict__ ms32, uint32_t lo,
-                                            uint32_t hi, double thr, float thr32) {
+                                            uint32_t hi, const double (&thr)[kPairR], const float (&thr32)[kPairR]) {
     if (lo >= hi) return;
     float ca[DIM], cb[DIM];
 #pragma unroll
@@ -425,7 +425,8 @@ __device__ __forceinline__ void pairs_range(const PrmArgs& a, PairStage& st, uin
 template <int DIM>
 __global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, const double* __restrict__ ms,
                                                                   const float* __restrict__ ms32, uint32_t j0, uint32_t j1,
-                                                                  double thr, float thr32) {
+                                                                  double thr_all, float thr32_all, const double* __restrict__ thr_row,
+                                                                  const float* __restrict__ thr32_row) {
     __shared__ uint2 stage[kPairThreads / 64][kStage];
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t jb0 = j0 + blockIdx.y * kPairJB;                 // first j of this block
@@ -447,6 +448,16 @@ __global__ __launch_bounds__(kPairThreads) void prm_pairs_kernel(PrmArgs a, cons
     for (int r2 = 0; r2 < kPairR / 2; ++r2)
 #pragma unroll
         for (int k = 0; k < DIM; ++k) cj32[r2][k] = pair_f32x2{(float)cj[2 * r2][k], (float)cj[2 * r2 + 1][k]};
+    // the radius rule has one threshold for every pair; the k-nearest variant's candidate search gives every row j its own
+    // (thr_row[j]: a radius expected to hold several times k earlier milestones)
+    double thr[kPairR];
+    float thr32[kPairR];
+#pragma unroll
+    for (int r = 0; r < kPairR; ++r) {
+        const bool row = thr_row != nullptr && jr[r] < jb1;
+        thr[r] = row ? thr_row[jr[r]] : thr_all;
+        thr32[r] = row ? thr32_row[jr[r]] : thr32_all;
+    }
     PairStage st{stage[tid >> 6], 0u};
     // i below every j of the block: no index test; the rest of the range (the diagonal blocks) tests i < j
     const uint32_t i_mid = i_hi < jb0 ? i_hi : (i_lo > jb0 ? i_lo : jb0);
@@ -483,6 +494,117 @@ __global__ __launch_bounds__(256) void prm_edge_kernel(DevParams p, PrmArgs a, u
         const uint32_t slot = base + 2u * (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         a.keys[slot] = ((uint64_t)pr.x << key_shift) | pr.y;       // i in j's list
         a.keys[slot + 1] = ((uint64_t)pr.y << key_shift) | pr.x;   // j in i's list (prm.rs:143-145)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3b. the k-NEAREST variant (BASELINE.json configs[4]: "all-pairs k-NN"; the reference connects by radius): milestone j's
+// candidates are the k earlier milestones nearest to it by (distance, index) instead of all within the radius.  The pair search
+// above runs with a per-row radius expected to hold several times k earlier milestones; its hits, sorted by (j, i), are cut down
+// to each row's k nearest here -- by the reference's own distance (sqrt of the sequential sum, rvss.rs:137-155), the lower index
+// first among equal distances -- and a row whose radius held fewer than k gets the exact search over all earlier milestones.
+__global__ __launch_bounds__(256) void prm_cand_keys_kernel(const uint2* __restrict__ cand, uint32_t n, uint32_t shift, uint64_t* __restrict__ keys) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n) keys[c] = ((uint64_t)cand[c].x << shift) | cand[c].y;
+}
+
+template <int DIM>
+__device__ __forceinline__ double prm_pair_distance(const double* __restrict__ ms, uint32_t j, uint32_t i) {
+    const double d0 = ms[(size_t)j * DIM] - ms[(size_t)i * DIM];   // distance(q_rand, other): the new milestone first
+    double acc = d0 * d0;
+#pragma unroll
+    for (int k = 1; k < DIM; ++k) {
+        double d = ms[(size_t)j * DIM + k] - ms[(size_t)i * DIM + k];
+        d = d * d;
+        acc = acc + d;
+    }
+    return sqrt(acc);
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void prm_knn_dist_kernel(PrmArgs a, const uint64_t* __restrict__ sorted, uint32_t n, uint32_t shift,
+                                                            double* __restrict__ dist) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const uint64_t key = sorted[c];
+    dist[c] = prm_pair_distance<DIM>(a.ms, (uint32_t)(key >> shift), (uint32_t)(key & ((1ull << shift) - 1ull)));
+}
+
+// one thread per row: its segment of the sorted candidates, k passes of "the next (distance, index) after the last one taken".
+// counters[0] = pairs selected so far (one atomic per wave), counters[1] = rows whose segment holds fewer than min(k, j) pairs
+__global__ __launch_bounds__(256) void prm_knn_select_kernel(const uint64_t* __restrict__ sorted, const double* __restrict__ dist, uint32_t n_sorted,
+                                                              uint32_t shift, uint32_t j0, uint32_t j1, uint32_t k, uint2* __restrict__ sel,
+                                                              uint32_t* counters, uint32_t* __restrict__ failed_rows) {
+    const uint32_t j = j0 + blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const bool row = j < j1 && j > 0;
+    const uint32_t need = row ? (k < j ? k : j) : 0u;
+    uint32_t lo = 0, hi = 0;
+    if (row) {
+        const uint64_t k0 = (uint64_t)j << shift, k1 = (uint64_t)(j + 1u) << shift;
+        uint32_t a0 = 0, b0 = n_sorted;
+        while (a0 < b0) { const uint32_t mid = a0 + ((b0 - a0) >> 1); if (sorted[mid] < k0) a0 = mid + 1; else b0 = mid; }
+        lo = a0;
+        b0 = n_sorted;
+        while (a0 < b0) { const uint32_t mid = a0 + ((b0 - a0) >> 1); if (sorted[mid] < k1) a0 = mid + 1; else b0 = mid; }
+        hi = a0;
+    }
+    const bool failed = row && hi - lo < need;
+    if (failed) failed_rows[atomicAdd(&counters[1], 1u)] = j;
+    const uint32_t take = failed ? 0u : need;
+    // wave prefix of `take`, one atomic per wave
+    uint32_t pre = take;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)pre, d, 64);
+        if (lane >= (uint32_t)d) pre += o;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)pre, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(&counters[0], total);
+    base = (uint32_t)__shfl((int)base, 63, 64) + pre - take;
+    const uint64_t mask = (1ull << shift) - 1ull;
+    double last_d = -1.0;
+    uint32_t last_i = 0;
+    bool first = true;
+    for (uint32_t t = 0; t < take; ++t) {
+        double best_d = __builtin_inf();
+        uint32_t best_i = 0xFFFFFFFFu;
+        for (uint32_t c = lo; c < hi; ++c) {
+            const double d = dist[c];
+            const uint32_t i = (uint32_t)(sorted[c] & mask);
+            const bool after = first || d > last_d || (d == last_d && i > last_i);
+            const bool better = d < best_d || (d == best_d && i < best_i);
+            if (after && better) { best_d = d; best_i = i; }
+        }
+        sel[base + t] = make_uint2(j, best_i);
+        last_d = best_d;
+        last_i = best_i;
+        first = false;
+    }
+}
+
+// one wave per row the radius failed: the exact k nearest among ALL earlier milestones, k rounds of the lexicographic minimum
+template <int DIM>
+__global__ __launch_bounds__(64) void prm_knn_brute_kernel(PrmArgs a, const uint32_t* __restrict__ failed_rows, uint32_t k, uint2* __restrict__ sel,
+                                                            uint32_t* counters) {
+    const uint32_t j = failed_rows[blockIdx.x], lane = threadIdx.x;
+    const uint32_t need = k < j ? k : j;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&counters[0], need);
+    base = uni(base);
+    double last_d = -1.0;
+    uint32_t last_i = 0;
+    for (uint32_t t = 0; t < need; ++t) {
+        Exact e{__builtin_inf(), 0xFFFFFFFFu};
+        for (uint32_t i = lane; i < j; i += 64) {
+            const double d = prm_pair_distance<DIM>(a.ms, j, i);
+            const bool after = t == 0 || d > last_d || (d == last_d && i > last_i);
+            if (after && (d < e.dist || (d == e.dist && i < e.idx))) { e.dist = d; e.idx = i; }
+        }
+        e = exact_wave_reduce(e);
+        if (lane == 0) sel[base + t] = make_uint2(j, e.idx);
+        last_d = unid(e.dist);
+        last_i = uni(e.idx);
     }
 }
 
@@ -565,7 +687,14 @@ __global__ void prm_shadow_kernel(const double* __restrict__ ms, float* __restri
     if (i < last) ms32[i] = (float)ms[i];
 }
 
-void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_t j1, double thr, hipStream_t s) {
+float prm_screen_threshold(const DevParams& p, double thr) {
+    double m = 0.0;
+    for (uint32_t k = 0; k < p.dim; ++k) m = std::fmax(m, std::fmax(std::fabs(p.lo[k]), std::fabs(p.hi[k])));
+    return host_screen_threshold(m, (int)p.dim, thr);
+}
+
+void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_t j1, double thr, hipStream_t s, const double* thr_row,
+                      const float* thr32_row) {
     if (j1 <= j0 || j1 < 2) return;
     // fl32 shadow of the new milestones (the older ones have theirs), then the screen threshold: milestones are samples
     // inside the bounds, so the magnitude bound M of the error model (rrt_device.hpp) is the bounds'
@@ -580,7 +709,7 @@ void launch_prm_pairs(const DevParams& p, const PrmArgs& a, uint32_t j0, uint32_
     dim_dispatch(p.dim, [&](auto d) {
         constexpr int D = decltype(d)::value;
         hipLaunchKernelGGL(prm_pairs_kernel<D>, dim3(ichunks, jblocks), dim3(kPairThreads), 0, s, a, (const double*)a.ms,
-                           (const float*)a.ms32, j0, j1, thr, thr32);
+                           (const float*)a.ms32, j0, j1, thr, thr32, thr_row, thr32_row);
     });
 }
 
@@ -597,6 +726,29 @@ void launch_prm_edges(const DevParams& p, const PrmArgs& a, uint32_t n_cand, hip
     dim_dispatch(p.dim, [&](auto d) {
         constexpr int D = decltype(d)::value;
         hipLaunchKernelGGL(prm_edge_kernel<D>, dim3((n_cand + 255) / 256), dim3(256), 0, s, p, a, n_cand, shift);
+    });
+}
+
+void launch_prm_knn_keys(const PrmArgs& a, uint32_t n_cand, uint64_t* keys, hipStream_t s) {
+    if (n_cand) hipLaunchKernelGGL(prm_cand_keys_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, s, (const uint2*)a.cand, n_cand, prm_key_shift(a.cap), keys);
+}
+void launch_prm_knn_select(const DevParams& p, const PrmArgs& a, const uint64_t* sorted, double* dist, uint32_t n_sorted, uint32_t j0, uint32_t j1,
+                           uint32_t k, uint2* sel, uint32_t* counters, uint32_t* failed_rows, hipStream_t s) {
+    const uint32_t shift = prm_key_shift(a.cap);
+    if (n_sorted)
+        dim_dispatch(p.dim, [&](auto d) {
+            constexpr int D = decltype(d)::value;
+            hipLaunchKernelGGL(prm_knn_dist_kernel<D>, dim3((n_sorted + 255) / 256), dim3(256), 0, s, a, sorted, n_sorted, shift, dist);
+        });
+    hipLaunchKernelGGL(prm_knn_select_kernel, dim3((j1 - j0 + 255) / 256), dim3(256), 0, s, sorted, (const double*)dist, n_sorted, shift, j0, j1, k,
+                       sel, counters, failed_rows);
+}
+void launch_prm_knn_brute(const DevParams& p, const PrmArgs& a, const uint32_t* failed_rows, uint32_t n_failed, uint32_t k, uint2* sel,
+                          uint32_t* counters, hipStream_t s) {
+    if (n_failed == 0) return;
+    dim_dispatch(p.dim, [&](auto d) {
+        constexpr int D = decltype(d)::value;
+        hipLaunchKernelGGL(prm_knn_brute_kernel<D>, dim3(n_failed), dim3(64), 0, s, a, failed_rows, k, sel, counters);
     });
 }
 

@@ -124,11 +124,11 @@ def config5():
                                      keep_clear=[start, goal]), boxes=None)
 
 
-def make_prm(sc, max_milestones=None, seed=42, stream=0, device=0, timeout=0.0, connection_radius=None):
+def make_prm(sc, max_milestones=None, seed=42, stream=0, device=0, timeout=0.0, connection_radius=None, knn_k=0):
     """Build a PRMRoadmap for a scenario dict and run Planner::setup."""
     from .capi import PRMRoadmap
     g = PRMRoadmap(sc["dim"], sc["bounds"], connection_radius or sc["connection_radius"],
-                   max_milestones or sc["max_milestones"], timeout, sc["lvs_fraction"], 0, seed, stream, device)
+                   max_milestones or sc["max_milestones"], timeout, sc["lvs_fraction"], 0, seed, stream, device, knn_k)
     if sc["spheres"] is not None:
         g.set_spheres(*sc["spheres"])
     if sc["boxes"] is not None:

@@ -105,6 +105,8 @@ pub struct OxhipPrmConfig {
     pub max_samples: u64,
     pub seed: u64,
     pub stream: u64,
+    pub knn_k: u32,
+    pub reserved: u32,
 }
 
 /// (field, byte offset, byte size) of `oxhip_prm_config`
@@ -120,8 +122,10 @@ pub const OXHIP_PRM_CONFIG_LAYOUT: &[(&str, usize, usize)] = &[
     ("max_samples", 168, 8),
     ("seed", 176, 8),
     ("stream", 184, 8),
+    ("knn_k", 192, 4),
+    ("reserved", 196, 4),
 ];
-pub const OXHIP_PRM_CONFIG_SIZE: usize = 192;
+pub const OXHIP_PRM_CONFIG_SIZE: usize = 200;
 
 /// opaque handles (owned by the library; freed with the matching `_destroy`)
 #[repr(C)]
@@ -202,6 +206,7 @@ extern "C" {
         n_goal: *mut u32,
     ) -> i32;
     pub fn oxhip_prm_last_timing(p: *mut OxhipPrm, phase_ms: *mut f64, n_candidates: *mut u64, redraw_batches: *mut u32) -> i32;
+    pub fn oxhip_prm_knn_exact_rows(p: *mut OxhipPrm, rows: *mut u32) -> i32;
 }
 
 #[cfg(test)]
@@ -229,6 +234,6 @@ mod tests {
             [struct_size, dim, bounds, max_distance, goal_bias, lvs_fraction, n_problems, max_nodes, stop_at_goal, kernel,
              seed, first_problem_id, device, planner, search_radius, space, goal_sampler, debug_flags, star_pool_share, frozen_split, reserved]);
         check_layout!(OxhipPrmConfig, OXHIP_PRM_CONFIG_LAYOUT, OXHIP_PRM_CONFIG_SIZE,
-            [struct_size, dim, bounds, timeout, connection_radius, lvs_fraction, max_milestones, device, max_samples, seed, stream]);
+            [struct_size, dim, bounds, timeout, connection_radius, lvs_fraction, max_milestones, device, max_samples, seed, stream, knn_k, reserved]);
     }
 }

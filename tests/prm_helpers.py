@@ -36,4 +36,6 @@ def make_oracle_prm(P, **kw):
     if P["boxes"]:
         lo, hi = params_boxes(P)
         o.set_boxes(lo, hi)
+    if P.get("knn_k"):
+        o.set_knn(P["knn_k"])
     return o

@@ -27,7 +27,7 @@ def test_header_and_binding_export_the_same_symbols(L):
         assert hasattr(L, name), name
     assert L.oxhip_abi_version() == capi.ABI_VERSION == 2
     assert C.sizeof(capi.Config) == 232  # layout of oxhip_rrt_config on the ABI
-    assert C.sizeof(capi.PrmConfig) == 192  # oxhip_prm_config
+    assert C.sizeof(capi.PrmConfig) == 200  # oxhip_prm_config
 
 
 def test_status_strings_cover_planning_error(L):

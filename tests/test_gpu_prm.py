@@ -340,3 +340,75 @@ def test_radius_screen_margin_sweep():
             assert np.array_equal(gs.view(np.uint64), os_.view(np.uint64)), (eps, sign)
             assert np.array_equal(goff, ooff) and np.array_equal(gn, on), (eps, sign)
             g.close()
+
+
+# ---------------------------------------------------------------------------------------- the k-nearest variant
+# BASELINE.json configs[4] words the roadmap as "all-pairs k-NN"; the reference connects by radius (prm.rs:131-138).  The variant
+# (oxhip_prm_config.knn_k): a new milestone connects to its k nearest EARLIER milestones by (distance, index), visited in ascending
+# index order -- defined in oracle/prm_oracle.c and, independently, tests/golden/make_golden_prm_knn.py.
+@pytest.fixture(scope="module")
+def prm_knn_golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prm_knn_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("key", ["wall_k6", "r3_k10", "r6_k8", "wall_k1"])
+def test_prm_knn_golden_scenes(prm_knn_golden, key):
+    P, R = prm_knn_golden[key]["params"], prm_knn_golden[key]["run"]
+    q0 = R["queries"][0]
+    g = make_gpu_prm(P, knn_k=P["knn_k"])
+    o = make_oracle_prm(P)
+    for x in (g, o):
+        x.setup(q0["start"], q0["goal_c"], q0["goal_r"])
+    g.construct_roadmap()
+    o.construct_roadmap(P["max_milestones"], P["max_samples"])
+    gs, goff, gn = assert_same_roadmap(g, o)
+    assert len(gn) == R["edge_entries"] and "%016x" % csr_checksum(goff, gn) == R["csr_checksum"]
+    assert "%016x" % states_checksum(gs) == R["states_checksum"]
+    for i, want in enumerate(R["edges_head"]):
+        assert list(gn[int(goff[i]):int(goff[i + 1])]) == want
+    for q in R["queries"]:
+        g.set_problem(q["start"], q["goal_c"], q["goal_r"])
+        o.set_problem(q["start"], q["goal_c"], q["goal_r"])
+        st, path = assert_same_query(g, o)
+        assert STATUS_NAME[st] == q["status"]
+    g.close()
+
+
+@pytest.mark.parametrize("k", [1, 8, 33])
+def test_prm_knn_doubling_rounds_and_thin_free_space(k):
+    """(i) with a wall clock the roadmap grows in doubling rounds: rows of a later round pick their neighbours among ALL earlier
+    milestones; (ii) a free space that is a thin slab breaks the isotropic density estimate behind the candidate radius, so many rows
+    fall short and take the exact search -- both must give the oracle's roadmap"""
+    slab = dict(dim=3, bounds=[(0.0, 10.0)] * 3, radius=0.7, fraction=0.05, spheres=[], seed=5, stream=3, max_milestones=3000, max_samples=10 ** 9,
+                boxes=[([0.0, 0.0, 0.0], [10.0, 10.0, 4.96]), ([0.0, 0.0, 5.0], [10.0, 10.0, 10.0])])
+    g = make_gpu_prm(slab, knn_k=k, timeout=3600.0)   # (a timeout makes construction run in doubling rounds)
+    o = make_oracle_prm(dict(slab, knn_k=k))
+    for x in (g, o):
+        x.setup([1.0, 1.0, 4.98], [9.0, 9.0, 4.98], 0.5)
+    g.construct_roadmap()
+    o.construct_roadmap(slab["max_milestones"])
+    assert_same_roadmap(g, o)
+    if k == 8:
+        assert g.knn_exact_rows() > 0      # the estimate did fall short somewhere: the exact search ran
+    assert_same_query(g, o)
+    g.close()
+
+
+def test_prm_knn_config5_full_size_whole_roadmap_equals_oracle():
+    """BASELINE.json configs[4] as worded: R^6, 50,000 milestones, k = 8 nearest + edge validity -- the whole roadmap against the oracle"""
+    sc = scenarios.config5()
+    g = scenarios.make_prm(sc, knn_k=8)
+    g.construct_roadmap()
+    o = orc.OraclePRM(6, sc["bounds"], sc["connection_radius"], lvs_fraction=0.05, seed=42, stream=0)
+    o.set_spheres(*sc["spheres"])
+    o.set_knn(8)
+    o.setup(sc["start"], sc["goal_centre"], sc["goal_radius"])
+    o.construct_roadmap(sc["max_milestones"])
+    assert_same_roadmap(g, o)
+    t = g.last_timing()
+    print("k-NN PRM 50,000 x R^6, k = 8: phases (ms) %s, candidates %d, exact rows %d" % (["%.3f" % v for v in t["phase_ms"]], t["candidates"], g.knn_exact_rows()))
+    assert_same_query(g, o)
+    g.close()

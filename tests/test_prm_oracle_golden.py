@@ -10,8 +10,19 @@ from helpers import unhex, bits, params_spheres, params_boxes, is_path_valid
 from prm_helpers import csr_checksum, states_checksum, make_oracle_prm, STATUS_NAME
 
 
-@pytest.mark.parametrize("key", ["wall", "r3", "r6", "sample_cap"])
-def test_prm_oracle_matches_numpy_restatement(prm_golden, key):
+@pytest.fixture(scope="module")
+def prm_knn_golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prm_knn_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("key", ["wall", "r3", "r6", "sample_cap", "knn:wall_k6", "knn:r3_k10", "knn:r6_k8", "knn:wall_k1"])
+def test_prm_oracle_matches_numpy_restatement(prm_golden, prm_knn_golden, key):
+    """radius connection (the reference, prm.rs:131-138) and the k-nearest variant (tests/golden/make_golden_prm_knn.py)"""
+    if key.startswith("knn:"):
+        prm_golden, key = prm_knn_golden, key[4:]
     P, R = prm_golden[key]["params"], prm_golden[key]["run"]
     q0 = R["queries"][0]
     o = make_oracle_prm(P)
