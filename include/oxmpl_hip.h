@@ -148,7 +148,7 @@ typedef struct oxhip_rrt_config {
                                            store); 0 = default: 64 x tree capacity, bounded so that the whole batch stays below 24 GB.
                                            The size bounds memory, never results: lists that do not fit are wired in further rounds */
     uint32_t frozen_split;              /* OXHIP_KERNEL_CELLS, solve(freeze = 1): waves a problem's frozen iterations are divided over
-                                           (1 .. 8; 0 = automatic: enough to fill the chip).  Results do not depend on it */
+                                           (1 .. 64; 0 = automatic).  Results do not depend on it */
     uint32_t reserved;                  /* 0 */
 } oxhip_rrt_config;
 

@@ -114,7 +114,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (cfg->kernel == OXHIP_KERNEL_RETIRED_3 || cfg->kernel == OXHIP_KERNEL_RETIRED_4)
         return fail(OXHIP_ERR_BAD_ARG, "kernel kinds 3 (box-pruned scan) and 4 (lane-group resolver) were retired in ABI version 2");
     if (cfg->planner > OXHIP_PLANNER_RRT_STAR) return fail(OXHIP_ERR_BAD_ARG, "unknown planner kind");
-    if (cfg->frozen_split > 8) return fail(OXHIP_ERR_BAD_ARG, "frozen_split must be 0 (automatic) or 1 .. 8");
+    if (cfg->frozen_split > 64) return fail(OXHIP_ERR_BAD_ARG, "frozen_split must be 0 (automatic) or 1 .. 64");
     if (cfg->kernel == OXHIP_KERNEL_CELLS && cfg->planner == OXHIP_PLANNER_RRT_CONNECT)
         return fail(OXHIP_ERR_BAD_ARG, "the cell-grid kernel runs RRT, and the geometry of the decoupled RRT*");
     if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT && cfg->kernel >= OXHIP_KERNEL_RESIDENT)
@@ -300,7 +300,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         if (e2 == hipSuccess) e2 = b->cell_xyz.alloc((size_t)P * cap * 4);
         if (e2 == hipSuccess) e2 = b->cell_meta.alloc(P);
         if (e2 == hipSuccess) e2 = b->cell_acc.alloc(P);
-        if (e2 == hipSuccess) e2 = b->cell_part_pos.alloc((size_t)P * 8);
+        if (e2 == hipSuccess) e2 = b->cell_part_pos.alloc((size_t)P * 64);
         if (e2 == hipSuccess) e2 = hipMemset(b->cell_meta.p, 0, (size_t)P * sizeof(CellMeta));
         if (e2 == hipSuccess) e2 = hipMemset(b->cell_acc.p, 0, (size_t)P * sizeof(CellAcc));
         if (e2 != hipSuccess) {

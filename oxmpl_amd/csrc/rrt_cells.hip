@@ -39,6 +39,8 @@ namespace oxhip {
 #endif
 constexpr uint32_t kBruteMax = OXHIP_CELLS_BRUTE;   // trees up to this size: every node, by index
 constexpr int kCellsWaves = 4;                       // waves (= problems, or parts of problems) per workgroup
+constexpr uint32_t kSelfSkipMax = 4;                 // up to this many parts, a part skips ahead to its start itself
+constexpr uint32_t kMaxSplit = 64;                   // parts a frozen launch of one problem is cut into, at most (cell_part_pos's row length)
 constexpr int kMaxShell = 6;                         // the cooperative search gives up beyond this ring (-> whole-tree path)
 #ifndef OXHIP_CELLS_NB
 #define OXHIP_CELLS_NB 4                             // neighbour cells in flight per trip
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         j_lo = (uint32_t)(((uint64_t)rounds * part) / split) * 64u;
         j_hi = (uint32_t)(((uint64_t)rounds * (part + 1u)) / split) * 64u;
         if (j_hi > budget_all) j_hi = budget_all;
-        pos_start = p.cell_part_pos[(size_t)prob * 8u + part];
+        if (split > kSelfSkipMax) pos_start = p.cell_part_pos[(size_t)prob * kMaxSplit + part];   // (else: found below)
     }
     const uint32_t budget = j_hi - j_lo;
 
@@ -566,6 +568,13 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
 
     RngWindow rng;
     rng.init(sh->rng_buf, p.seed, p.first_problem_id + prob, pos_start);
+    if (split > 1 && split <= kSelfSkipMax && j_lo > 0) {
+        // With few parts a part finds its own start: the sampler's position arithmetic over the queries in front of it (a goal
+        // sample draws one word, a uniform one 1 + D; nothing else is evaluated).  It runs in the shadow of the SIMD's other waves'
+        // memory stalls -- a separate pass over every problem before the launch (cells_prepare_kernel) cost 6 % of a steady launch.
+        for (uint32_t r0 = 0; r0 < j_lo; r0 += 64u) cells_sample_block<DIM, false>(rng, p, goal_c, goal_radius, 64u, lane, sh, r0);
+        pos_start = rng.pos;
+    }
     ProblemState st = st0;
     if (split > 1) { st.checksum = 0; st.accepted = 0; st.iterations = 0; }   // this part's own sums (combined at the end)
     uint64_t draws_done = pos_start;
@@ -1177,7 +1186,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         }
     }
 #undef OXHIP_CPHASE
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!p.freeze) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a frozen launch has stored nothing)
     if (split > 1) {
         // this part's sums into the problem's accumulator; the last part to arrive writes the state.
         // H_final = H0 P^N + sum_parts Hpart P^(N - j_hi)
@@ -1186,15 +1195,18 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         CellAcc& acc = p.cell_acc[prob];
         uint32_t arrived = 0;
         if (lane == 0) {
-            atomicAdd((unsigned long long*)&acc.chk, (unsigned long long)(st.checksum * w));
-            atomicAdd((unsigned long long*)&acc.accepted, (unsigned long long)st.accepted);
-            if (part == split - 1u) atomicExch((unsigned long long*)&acc.pos, (unsigned long long)draws_done);
-            __threadfence();
-            arrived = atomicAdd(&acc.done, 1u);
+            // No cache flush here (a device-scope fence writes back and invalidates the XCD's L2 -- per part, that cost more than
+            // the part's work at high splits): the sums travel by atomics, which execute at the coherence point, and the arrival
+            // counter is bumped only after their return values are back -- the empty asm makes the increment depend on them.
+            const unsigned long long r0 = atomicAdd((unsigned long long*)&acc.chk, (unsigned long long)(st.checksum * w));
+            const unsigned long long r1 = atomicAdd((unsigned long long*)&acc.accepted, (unsigned long long)st.accepted);
+            const unsigned long long r2 = part == split - 1u ? atomicExch((unsigned long long*)&acc.pos, (unsigned long long)draws_done) : 0ull;
+            uint32_t one = 1u;
+            asm volatile("" : "+v"(one) : "v"((uint32_t)r0), "v"((uint32_t)r1), "v"((uint32_t)r2));
+            arrived = atomicAdd(&acc.done, one);
         }
         arrived = uni(arrived);
         if (arrived == split - 1u && lane == 0) {
-            __threadfence();
             uint64_t pn = 1, b2 = kFnvPrime;
             for (uint32_t e = budget_all; e != 0; e >>= 1) { if (e & 1u) pn *= b2; b2 *= b2; }
             ProblemState out = st0;
@@ -1257,7 +1269,7 @@ __global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
         grid_store<DIM>(meta, g, n, mabs_bits, lane);
     }
     const uint32_t split = p.freeze ? p.cells_split : 1u;
-    if (split <= 1) return;
+    if (split <= kSelfSkipMax) return;   // (few parts find their own starts: rrt_cells_kernel)
     double goal_c[DIM];
 #pragma unroll
     for (int k = 0; k < DIM; ++k) goal_c[k] = p.goal_c[(size_t)prob * DIM + k];
@@ -1267,7 +1279,7 @@ __global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
     uint32_t next_part = 0;
     for (uint32_t r = 0; r < rounds; ++r) {
         while (next_part < split && (uint32_t)(((uint64_t)rounds * next_part) / split) == r) {
-            if (lane == 0) p.cell_part_pos[(size_t)prob * 8u + next_part] = rng.pos;
+            if (lane == 0) p.cell_part_pos[(size_t)prob * kMaxSplit + next_part] = rng.pos;
             ++next_part;
         }
         if (next_part >= split) break;
@@ -1275,7 +1287,7 @@ __global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
         cells_sample_block<DIM, false>(rng, p, goal_c, p.goal_r[prob], m, lane, &shw, r * 64u);
     }
     while (next_part < split) {   // (parts without a round start where the stream ends)
-        if (lane == 0) p.cell_part_pos[(size_t)prob * 8u + next_part] = rng.pos;
+        if (lane == 0) p.cell_part_pos[(size_t)prob * kMaxSplit + next_part] = rng.pos;
         ++next_part;
     }
 }
