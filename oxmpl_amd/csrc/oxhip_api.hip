@@ -296,7 +296,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         if (split == 0) { split = (2048u + P - 1u) / P; if (split > 8u) split = 8u; if (split < 1u) split = 1u; }
         dp.cells_split = split;
         hipError_t e2 = b->cell_blk.alloc((size_t)P * dp.cell_blocks);
-        if (e2 == hipSuccess) e2 = b->cell_flat.alloc((size_t)P * 1024 * 4);
+        if (e2 == hipSuccess) e2 = b->cell_flat.alloc((size_t)P * 4096 * 4);
         if (e2 == hipSuccess) e2 = b->cell_xyz.alloc((size_t)P * cap * 4);
         if (e2 == hipSuccess) e2 = b->cell_meta.alloc(P);
         if (e2 == hipSuccess) e2 = b->cell_acc.alloc(P);

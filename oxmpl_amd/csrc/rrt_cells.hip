@@ -38,6 +38,8 @@ namespace oxhip {
 #define OXHIP_CELLS_BRUTE 1024
 #endif
 constexpr uint32_t kBruteMax = OXHIP_CELLS_BRUTE;   // trees up to this size: every node, by index
+constexpr uint32_t kFlatCap = 4096;                  // entries of a problem's flat list (oxhip_api.hip allocates them)
+static_assert(kBruteMax <= kFlatCap, "the flat list holds the small trees");
 constexpr int kCellsWaves = 4;                       // waves (= problems, or parts of problems) per workgroup
 constexpr uint32_t kSelfSkipMax = 4;                 // up to this many parts, a part skips ahead to its start itself
 constexpr uint32_t kMaxSplit = 64;                   // parts a frozen launch of one problem is cut into, at most (cell_part_pos's row length)
@@ -175,7 +177,7 @@ __device__ __forceinline__ void cells_build(const DevParams& p, uint32_t prob, u
     const double* tree = p.tree + (size_t)prob * DIM * cap;
     const uint8_t* skip = p.skip + (size_t)prob * cap;
     CellBlock* blk = p.cell_blk + (size_t)prob * p.cell_blocks;
-    cfloat4* flat = reinterpret_cast<cfloat4*>(p.cell_flat) + (size_t)prob * kBruteMax;
+    cfloat4* flat = reinterpret_cast<cfloat4*>(p.cell_flat) + (size_t)prob * kFlatCap;
     cdouble4* xyz = reinterpret_cast<cdouble4*>(p.cell_xyz) + (size_t)prob * cap;
     double lo[DIM], hi[DIM];
 #pragma unroll
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
     int32_t* parent = p.parent + (size_t)prob * cap;
     uint8_t* skip = p.skip + (size_t)prob * cap;
     CellBlock* blk = p.cell_blk + (size_t)prob * p.cell_blocks;
-    cfloat4* flat = reinterpret_cast<cfloat4*>(p.cell_flat) + (size_t)prob * kBruteMax;
+    cfloat4* flat = reinterpret_cast<cfloat4*>(p.cell_flat) + (size_t)prob * kFlatCap;
     cdouble4* xyz = reinterpret_cast<cdouble4*>(p.cell_xyz) + (size_t)prob * cap;
     double goal_c[D];
 #pragma unroll
@@ -1003,7 +1005,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
                     const uint32_t cell = cell_place<DIM>(grid, qn, idx, entry, tf, err);
                     const bool link = mine && ok && !dup;
                     if (grid.level == 0) {
-                        if (mine && ok && idx < kBruteMax)
+                        if (mine && ok && idx < kFlatCap)
                             flat[idx] = link ? cfloat4{tf[0], tf[1], tf[2], 0.0f} : cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f};
                     } else {
                         cells_insert(blk, grid.pool_next, cell, entry, link, lane);
@@ -1163,7 +1165,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
                         xyz[i] = cdouble4{qn1[0], qn1[1], D >= 3 ? qn1[D - 1] : 0.0, 0.0};
                         parent[i] = (int32_t)nearest1;
                         skip[i] = dup1 ? 1 : 0;
-                        if (grid.level == 0 && i < kBruteMax)
+                        if (grid.level == 0 && i < kFlatCap)
                             flat[i] = dup1 ? cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f} : cfloat4{tf[0], tf[1], tf[2], 0.0f};
                     }
                     if (grid.level != 0) cells_insert(blk, grid.pool_next, cell, entry, lane == 0 && !dup1, lane);

@@ -140,7 +140,7 @@ struct DevParams {
     const double* goal_r;   // [P] goal radii as given (the disc sampler scales by them)
     // rrt_cells.hip
     CellBlock* cell_blk;     // [P][cell_blocks]: head blocks (one per cell of the finest grid), then the overflow blocks
-    float* cell_flat;        // [P][1024][4]: trees of up to 1,024 nodes as a flat list (tx, ty, tz, -): positions in cell units
+    float* cell_flat;        // [P][4096][4]: small trees (up to 1,024 nodes) as a flat list (tx, ty, tz, -): positions in cell units
     double* cell_xyz;        // [P][cap][4]: the tree's binary64 coordinates once more, node-major (one 32-byte access per winner)
     CellMeta* cell_meta;     // [P]
     CellAcc* cell_acc;       // [P] zero between launches
