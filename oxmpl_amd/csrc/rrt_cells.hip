@@ -653,21 +653,54 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
             verdict = cells_verdict(t2, __builtin_inf(), A);
             OXHIP_CPHASE(7);   // (the flat scan of a small tree)
         } else {
-            // (1) the query's own cell
-            cell_visit<DIM>(blk, (cq[2] * grid.G[1] + cq[1]) * grid.G[0] + cq[0], act, cq, tq, t2);
-            if (STAMP) ++n_steps;
-            // (2) of the other 3^D - 1 cells only those whose box comes within (d1 + 2A) of the query: every node of a skipped
-            //     cell is farther than that, so it can neither beat nor tie with the final winner (whose d1 can only shrink)
-            float thr2;
-            {
-                const double dd = sqrt((double)t2.s1) * (1.0 + 0x1p-20) + 2.0 * A;
-                thr2 = t2.s1 < __builtin_inff() ? f32_up(dd * dd * (1.0 + 0x1p-20)) : __builtin_inff();
-            }
+            // (1) the query's own cell and, in the same trip, the NEARER face cell along every axis: together they almost always
+            //     hold the nearest node, so the bound that prunes the other cells is tight from the start
             float gap_lo[3], gap_hi[3];   // distance (cell units) from the query to its cell's low / high face along each axis
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 gap_lo[k] = fmaxf(tq[k] - (float)cq[k], 0.0f) * (1.0f - 0x1p-20f);
                 gap_hi[k] = fmaxf((float)(cq[k] + 1u) - tq[k], 0.0f) * (1.0f - 0x1p-20f);
+            }
+            uint32_t done_faces = 0;   // bits of `need` (faces come first there: -x +x -y +y -z +z) visited in this trip
+            {
+                cuint4 vo[4], vf[DIM][4];
+                uint32_t fc[DIM][3];
+                bool fon[DIM];
+                block_load(blk, act ? (cq[2] * grid.G[1] + cq[1]) * grid.G[0] + cq[0] : 0u, vo);
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    const bool up = gap_hi[a] < gap_lo[a];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) fc[a][k] = cq[k] + (k == a ? (up ? 1u : 0xFFFFFFFFu) : 0u);
+                    fon[a] = act && (up ? cq[a] + 1u < grid.G[a] : cq[a] > 0u);
+                    done_faces |= fon[a] ? (1u << (2 * a + (up ? 1 : 0))) : 0u;
+                    block_load(blk, fon[a] ? (fc[a][2] * grid.G[1] + fc[a][1]) * grid.G[0] + fc[a][0] : 0u, vf[a]);
+                }
+                {
+                    float off[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) off[k] = ((float)cq[k] + 0x1p-17f) - tq[k];
+                    const uint32_t cnt = act ? vo[0][0] : 0u;
+                    block_eval<DIM>(vo, cnt < kBlkEntries ? cnt : kBlkEntries, off, t2);
+                    if (__ballot(cnt > kBlkEntries) != 0) chain_follow<DIM>(blk, vo[0][1], cnt, act, off, t2);
+                }
+#pragma unroll
+                for (int a = 0; a < DIM; ++a) {
+                    float off[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) off[k] = ((float)fc[a][k] + 0x1p-17f) - tq[k];
+                    const uint32_t cnt = fon[a] ? vf[a][0][0] : 0u;
+                    block_eval<DIM>(vf[a], cnt < kBlkEntries ? cnt : kBlkEntries, off, t2);
+                    if (__ballot(cnt > kBlkEntries) != 0) chain_follow<DIM>(blk, vf[a][0][1], cnt, fon[a], off, t2);
+                }
+            }
+            if (STAMP) ++n_steps;
+            // (2) of the other cells only those whose box comes within (d1 + 2A) of the query: every node of a skipped
+            //     cell is farther than that, so it can neither beat nor tie with the final winner (whose d1 can only shrink)
+            float thr2;
+            {
+                const double dd = sqrt((double)t2.s1) * (1.0 + 0x1p-20) + 2.0 * A;
+                thr2 = t2.s1 < __builtin_inff() ? f32_up(dd * dd * (1.0 + 0x1p-20)) : __builtin_inff();
             }
             // bit b of `need` = the b-th neighbour in the order faces, edges, corners (kOrder: b -> o = (dz + 1) 9 + (dy + 1) 3 +
             // (dx + 1)): the cells most likely to hold the nearest node come first, and the bound shrinks trip by trip
@@ -689,7 +722,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
                 }
                 return mask;
             };
-            uint32_t need = needed(thr2);
+            uint32_t need = needed(thr2) & ~done_faces;
             // a lane's next needed cells, NB cells in flight per trip
             while (__ballot(need != 0) != 0) {
                 if (STAMP) ++n_steps;
