@@ -152,7 +152,8 @@ __device__ __forceinline__ void cells_insert(CellBlock* blk, uint32_t& pool_next
                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)entry, j);
         uint32_t b = cj;
         for (uint32_t t = 0; t < sj / kBlkEntries; ++t) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // (this wave's earlier link stores have landed: a wait, not a cache flush -- only this wave ever touches the problem's blocks)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             uint32_t nx = uni(__hip_atomic_load(&blk[b].next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (nx == 0) {
                 nx = pool_next++;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
     uint32_t jr = 0, js = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
     uint64_t n_rounds = 0, n_lanes = 0, n_amb = 0, n_expand = 0, n_cut_conflict = 0, n_tie = 0, n_memo = 0, n_forced = 0, n_regrid = 0, n_steps = 0;
-    uint64_t t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_pm = 0;
+    uint64_t t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_pm = 0, t_c[4] = {0, 0, 0, 0}, t_cm = 0;
     const uint64_t t_begin = STAMP ? (uint64_t)clock64() : 0;
 #define OXHIP_CPHASE(IDX) do { if (STAMP) { const uint64_t now_ = (uint64_t)clock64(); t_ph[IDX] += now_ - t_pm; t_pm = now_; } } while (0)
     // the last whole-tree answer: valid while the tree has not grown
@@ -636,18 +637,32 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
             // every node, by index: a coalesced load gives each lane one node of the next 64, then node after node is
             // broadcast from its lane (v_readlane -> scalar operands): no memory latency per node
             cfloat4 mine_nd = flat[lane < n ? lane : 0u];
+            // (four independent running pairs: with one wave on the SIMD a single chain of dependent min / med3 / select
+            //  instructions would wait out every instruction's latency)
+            Top2 ta[4] = {{__builtin_inff(), __builtin_inff(), kNoNode}, {__builtin_inff(), __builtin_inff(), kNoNode},
+                          {__builtin_inff(), __builtin_inff(), kNoNode}, {__builtin_inff(), __builtin_inff(), kNoNode}};
             for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                 const cfloat4 cur_nd = mine_nd;
                 const uint32_t nx = i0 + 64u + lane;
                 mine_nd = flat[nx < n ? nx : 0u];   // (the next 64 are on their way while these are processed)
                 const uint32_t cnt = n - i0 < 64u ? n - i0 : 64u;
-                for (uint32_t t = 0; t < cnt; ++t) {
-                    cfloat4 nd;
+                for (uint32_t t = 0; t < cnt; t += 4) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) nd[k] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(cur_nd[k]), (int)t));
-                    nd[3] = 0.0f;
-                    top2_push(t2, cell_s<DIM>(nd, tq), i0 + t);
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t tt = t + (uint32_t)u < cnt ? t + (uint32_t)u : cnt - 1u;   // (a repeated node changes nothing but s2 ...
+                        cfloat4 nd;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) nd[k] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(cur_nd[k]), (int)tt));
+                        nd[3] = 0.0f;
+                        const float sv = t + (uint32_t)u < cnt ? cell_s<DIM>(nd, tq) : __builtin_inff();   // ... so it is pushed as +inf)
+                        top2_push(ta[u], sv, i0 + tt);
+                    }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // fold the four pairs: a pair's second value is >= its first, so only its value matters
+                top2_push(t2, ta[u].s1, ta[u].i1);
+                top2_push(t2, ta[u].s2, kNoNode);
             }
             if (STAMP) n_steps += n;
             verdict = cells_verdict(t2, __builtin_inf(), A);
@@ -1017,6 +1032,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         if ((p.dbg_flags & OXHIP_DEBUG_ONE_LANE_ROUNDS) != 0 && cut > 1) { cut = 1; stop_after = -1; if (STAMP) ++n_forced; }
         OXHIP_CPHASE(4);   // prefix: cap, goal, conflicts
         // ---- commit lanes [0, cut) in query order
+        if (STAMP) t_cm = (uint64_t)clock64();
         if (cut > 0) {
             const uint64_t cutm = first_n_mask(cut);
             const bool mine = lane < cut;
@@ -1041,7 +1057,9 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
                         if (mine && ok && idx < kFlatCap)
                             flat[idx] = link ? cfloat4{tf[0], tf[1], tf[2], 0.0f} : cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f};
                     } else {
+                        if (STAMP) { const uint64_t nw = (uint64_t)clock64(); t_c[0] += nw - t_cm; t_cm = nw; }
                         cells_insert(blk, grid.pool_next, cell, entry, link, lane);
+                        if (STAMP) { const uint64_t nw = (uint64_t)clock64(); t_c[1] += nw - t_cm; t_cm = nw; }
                     }
                     const double e = -wave_min_f64(link ? -err : 0.0);
                     if (e > grid.delta_node) grid.delta_node = (double)f32_up(e * (1.0 + 1e-9));
@@ -1057,6 +1075,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
                     st.goal_node = (int32_t)__builtin_amdgcn_readlane((int)idx, __ffsll((unsigned long long)hits) - 1);
                 n += (uint32_t)__popcll(okm & cutm);
             }
+            if (STAMP) { const uint64_t nw = (uint64_t)clock64(); t_c[2] += nw - t_cm; t_cm = nw; }
             // checksum: H <- H P^cut + sum_{j < cut} g_j P^(cut-1-j)
             {
                 const uint64_t gd = iter_digest<D>(nearest, qn, DIM, ok);
@@ -1074,6 +1093,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
                                ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pos_after_l >> 32), (int)(cut - 1u)) << 32));
             jr += cut;
         }
+        if (STAMP) { const uint64_t nw = (uint64_t)clock64(); t_c[3] += nw - t_cm; t_cm = nw; }
         OXHIP_CPHASE(5);   // commit
         if (stop_after >= 0) { stop = stop_after; break; }
         if (cut == m || ambm == 0 || (uint32_t)(__ffsll((unsigned long long)ambm) - 1) != cut) continue;
@@ -1276,6 +1296,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
             atomicAdd((unsigned long long*)&p.dbg[15], (unsigned long long)n_tie);
             for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&p.dbg[32 + i], (unsigned long long)t_ph[i]);
             atomicAdd((unsigned long long*)&p.dbg[13], (unsigned long long)((uint64_t)clock64() - t_begin));
+            p.dbg[62] = t_c[0]; p.dbg[63] = t_c[1]; p.dbg[49] = t_c[2]; p.dbg[0] = t_c[3];
         }
     }
 }

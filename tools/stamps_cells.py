@@ -24,6 +24,7 @@ def show(tag, g, iters):
     print("   whole-tree events %d (ties %d), memo hits %d, shell searches %d, chain steps %d (%.1f per round), regrids %d, conflict cuts %d"
           % (int(s[4]), int(s[15]), int(s[11]), int(s[8]), int(s[9]), int(s[9]) / rounds, int(s[10]), int(s[12])))
     print("   batch-wide: whole-tree events %d, shell searches %d" % (int(s[54]), int(s[60])))
+    print("   commit split: before insert %d, insert (atomic) %d, reductions %d, checksum+rest %d per round" % tuple(int(v) // rounds for v in (s[62], s[63], s[49], s[0])))
 
 
 g = scenarios.make_batch(sc, P, 10000, False, 42, 0, 0, capi.KERNEL_CELLS, frozen_split=split)
