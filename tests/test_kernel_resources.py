@@ -136,7 +136,7 @@ def test_prm_pair_search_streams_the_i_side_through_scalar_loads(prm_asm):
     for name, m in meta.items():
         assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, name
         assert m["max_flat_workgroup_size"] == 256
-    body = prm_asm.split("prm_pairs_kernelILi6EEEvNS_7PrmArgsEPKdPKfjjdf:")[1].split("s_endpgm")[0]
+    body = re.split(r"prm_pairs_kernelILi6EEEvNS_7PrmArgsE\w*: ; @", prm_asm)[1].split("s_endpgm")[0]
     assert body.count("s_load_dwordx4") >= 2 and body.count("s_load_dwordx2") >= 2   # 6 floats per i, two register sets in flight
     assert "v_fma_f64" not in body
     # 4 milestones per thread = 2 packed registers per coordinate; per i and loop body: 12 subtractions, 2 squares, 10 fmas
