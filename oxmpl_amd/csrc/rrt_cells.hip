@@ -456,8 +456,11 @@ __device__ __forceinline__ int cells_verdict(const Top2& t, double lb, double A)
 #ifndef OXHIP_CELLS_WAVES_PER_EU
 #define OXHIP_CELLS_WAVES_PER_EU 2
 #endif
-template <int DIM, bool STAMP>
-__global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rrt_cells_kernel(DevParams p) {
+#ifndef OXHIP_CELLS_WAVES_PER_EU_FROZEN
+#define OXHIP_CELLS_WAVES_PER_EU_FROZEN 2   // the frozen specialisation (no insert, no prefix) of a steady-state launch
+#endif
+template <int DIM, bool STAMP, bool FROZEN>
+__global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU_FROZEN : OXHIP_CELLS_WAVES_PER_EU) void rrt_cells_kernel(DevParams p) {
     constexpr int D = DIM;
     __shared__ CellsShared<DIM> shared;
 
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
     const uint32_t wave = uni(tid >> 6), lane = tid & 63;
     // problems are dealt to the XCDs round-robin (workgroup w runs on XCD w % 8) and all parts of a problem stay on one XCD:
     // they share its L2 copy of the grid
-    const uint32_t split = p.freeze ? p.cells_split : 1u;
+    const uint32_t split = FROZEN ? p.cells_split : 1u;
     const uint32_t xcd = blockIdx.x & 7u, unit = (blockIdx.x >> 3) * (uint32_t)kCellsWaves + wave;
     const uint32_t prob = (unit / split) * 8u + xcd, part = unit % split;
 
@@ -598,8 +601,8 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
 
     while (true) {
         if (jr >= budget) { stop = 1; break; }
-        if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
-        if (!p.freeze && n >= grid.regrid_at) {   // the tree outgrew its grid: the next finer one
+        if (!FROZEN && n >= p.max_nodes) { stop = 2; break; }
+        if (!FROZEN && n >= grid.regrid_at) {   // the tree outgrew its grid: the next finer one
             cells_build<DIM>(p, prob, n, lane, c0, grid, mabs_bits);
             if (STAMP) ++n_regrid;
         }
@@ -952,7 +955,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         }
         OXHIP_CPHASE(3);   // motion check
         const bool ok = act && !bad;
-        const bool ins = !p.freeze;
+        constexpr bool ins = !FROZEN;
         float nf_a[D], nf_cc;
         {
             double sq = 0.0;
@@ -1102,7 +1105,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         //      by squared distances, the wave striding over the nodes: if exactly one node is within a rounding of the
         //      minimum, it is the reference's nearest node (sqrt is monotone).  Only a genuine near-tie -- two d2 that may
         //      share a correctly rounded root -- takes the reference's literal loop (post-sqrt compare, lowest index).
-        if (!p.freeze && n >= p.max_nodes) { stop = 2; break; }
+        if (!FROZEN && n >= p.max_nodes) { stop = 2; break; }
         {
             if (STAMP) ++n_amb;
             const uint32_t slot1 = jr & 63u;
@@ -1206,7 +1209,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
             bool hit1 = false;
             if (ok1) {
                 st.accepted++;
-                if (!p.freeze) {
+                if (!FROZEN) {
                     const uint32_t i = n;
                     float tf[3];
                     double err;
@@ -1241,7 +1244,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         }
     }
 #undef OXHIP_CPHASE
-    if (!p.freeze) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a frozen launch has stored nothing)
+    if (!FROZEN) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // (a frozen launch has stored nothing)
     if (split > 1) {
         // this part's sums into the problem's accumulator; the last part to arrive writes the state.
         // H_final = H0 P^N + sum_parts Hpart P^(N - j_hi)
@@ -1279,7 +1282,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, OXHIP_CELLS_WAVES_PER_EU) void rr
         st.stop_reason = stop;
         p.state[prob] = st;
     }
-    if (!p.freeze) grid_store<DIM>(meta, grid, n, mabs_bits, lane);
+    if (!FROZEN) grid_store<DIM>(meta, grid, n, mabs_bits, lane);
     if (STAMP && p.dbg && lane == 0) {
         atomicAdd((unsigned long long*)&p.dbg[54], (unsigned long long)n_amb);
         atomicAdd((unsigned long long*)&p.dbg[55], (unsigned long long)n_memo);
@@ -1370,8 +1373,13 @@ static void launch_cells_dim(const DevParams& p, hipStream_t stream) {
     const uint32_t per_xcd = (p.n_problems + 7u) / 8u;
     const uint32_t wgs_per_xcd = (per_xcd * split + (uint32_t)kCellsWaves - 1u) / (uint32_t)kCellsWaves;
     dim3 grid(8u * wgs_per_xcd), block(kCellsWaves * 64);
-    if (p.dbg) hipLaunchKernelGGL((rrt_cells_kernel<DIM, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((rrt_cells_kernel<DIM, false>), grid, block, 0, stream, p);
+    if (p.freeze) {
+        if (p.dbg) hipLaunchKernelGGL((rrt_cells_kernel<DIM, true, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((rrt_cells_kernel<DIM, false, true>), grid, block, 0, stream, p);
+    } else {
+        if (p.dbg) hipLaunchKernelGGL((rrt_cells_kernel<DIM, true, false>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((rrt_cells_kernel<DIM, false, false>), grid, block, 0, stream, p);
+    }
 }
 
 void launch_rrt_cells(const DevParams& p, hipStream_t stream) {
