@@ -47,6 +47,9 @@ constexpr int kMaxShell = 6;                         // the cooperative search g
 #ifndef OXHIP_CELLS_NB
 #define OXHIP_CELLS_NB 4                             // neighbour cells in flight per trip
 #endif
+#ifndef OXHIP_CELLS_TAIL
+#define OXHIP_CELLS_TAIL 64                          // at most this many outstanding (query, cell) pairs: one pair per lane (0: off)
+#endif
 
 typedef float cfloat4 __attribute__((ext_vector_type(4)));
 typedef uint32_t cuint4 __attribute__((ext_vector_type(4)));
@@ -69,6 +72,9 @@ struct CellsWaveLds {
     double newn[DIM][64];         // the round's would-be new nodes, by rank
     float newn32[64][4];          // ... as the dot-product pre-screen holds them: fl32(x - c0), fl32(|.|^2)
     float obs32_thr[64];          // the sphere pre-filter's thresholds (they carry this problem's magnitude bound)
+    uint32_t tail_pair[64];       // the tail pass: (owner lane | neighbour number << 8) of the k-th outstanding (query, cell) pair ...
+    float tail_s1[64], tail_s2[64];   // ... and what lane k found in that cell
+    uint32_t tail_i1[64];
 };
 template <int DIM>
 struct CellsShared {
@@ -353,10 +359,25 @@ __device__ __forceinline__ void cells_sample_block(RngWindow& rng, const DevPara
     }
 }
 
+// inclusive prefix sum over the wave (DPP: shifts within the rows of 16, then the row totals)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_scan_step(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+    v = dpp_scan_step<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_scan_step<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_scan_step<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_scan_step<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_scan_step<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+    v = dpp_scan_step<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 // smallest / second smallest screen value and the node holding the smallest
 struct Top2 {
     float s1, s2;
-    uint32_t i1;
+    uint32_t i1;   // node index << 16 (the lower bits are whatever the entry's word held)
 };
 __device__ __forceinline__ void top2_push(Top2& t, float s, uint32_t i) {
     const bool lt = s < t.s1;
@@ -379,23 +400,31 @@ __device__ __forceinline__ float cell_s(const cfloat4& nd, const float (&tq)[3])
     return s;
 }
 
-// one block (16 dwords: count, next, seven entries) against a query: the entries e < nvalid are pushed.  off = (cell + half a
-// bin) - query, so that a coordinate decodes with one fused multiply-add.
+// one block (16 dwords: count, next, seven entries) against a query: the entries e < nvalid are pushed, two at a time through
+// the packed binary32 pipe (v_pk_fma_f32 / v_pk_mul_f32: the same IEEE operations as the scalar forms).  off = (cell + half a
+// bin) - query, so that a coordinate decodes with one fused multiply-add.  Top2::i1 holds the entry's upper word as it is
+// stored -- the node index in its upper 16 bits -- and is shifted once, when the round's winner is read.
+typedef float cells_f32x2 __attribute__((ext_vector_type(2)));
 template <int DIM>
 __device__ __forceinline__ void block_eval(const cuint4 (&v)[4], uint32_t nvalid, const float (&off)[3], Top2& t2) {
+    const cells_f32x2 sc = {0x1p-16f, 0x1p-16f};
 #pragma unroll
-    for (int e = 0; e < (int)kBlkEntries; ++e) {
+    for (int e = 0; e < (int)kBlkEntries; e += 2) {
         if (__ballot((uint32_t)e < nvalid) == 0) break;   // (uniform)
-        const uint32_t lo = v[(2 + 2 * e) / 4][(2 + 2 * e) % 4], hi = v[(3 + 2 * e) / 4][(3 + 2 * e) % 4];
-        const float ex = __builtin_fmaf((float)(lo & 0xFFFFu), 0x1p-16f, off[0]);
-        const float ey = __builtin_fmaf((float)(lo >> 16), 0x1p-16f, off[1]);
-        float s = ex * ex;
-        s = __builtin_fmaf(ey, ey, s);
+        constexpr int kLast = (int)kBlkEntries - 1;
+        const int e1 = e + 1 <= kLast ? e + 1 : kLast;
+        const uint32_t lo0 = v[(2 + 2 * e) / 4][(2 + 2 * e) % 4], hi0 = v[(3 + 2 * e) / 4][(3 + 2 * e) % 4];
+        const uint32_t lo1 = v[(2 + 2 * e1) / 4][(2 + 2 * e1) % 4], hi1 = v[(3 + 2 * e1) / 4][(3 + 2 * e1) % 4];
+        const cells_f32x2 ex = __builtin_elementwise_fma(cells_f32x2{(float)(lo0 & 0xFFFFu), (float)(lo1 & 0xFFFFu)}, sc, cells_f32x2{off[0], off[0]});
+        const cells_f32x2 ey = __builtin_elementwise_fma(cells_f32x2{(float)(lo0 >> 16), (float)(lo1 >> 16)}, sc, cells_f32x2{off[1], off[1]});
+        cells_f32x2 s = ex * ex;
+        s = __builtin_elementwise_fma(ey, ey, s);
         if (DIM >= 3) {
-            const float ez = __builtin_fmaf((float)(hi & 0xFFFFu), 0x1p-16f, off[2]);
-            s = __builtin_fmaf(ez, ez, s);
+            const cells_f32x2 ez = __builtin_elementwise_fma(cells_f32x2{(float)(hi0 & 0xFFFFu), (float)(hi1 & 0xFFFFu)}, sc, cells_f32x2{off[2], off[2]});
+            s = __builtin_elementwise_fma(ez, ez, s);
         }
-        top2_push(t2, (uint32_t)e < nvalid ? s : __builtin_inff(), hi >> 16);
+        top2_push(t2, (uint32_t)e < nvalid ? s[0] : __builtin_inff(), hi0);
+        if (e + 1 <= kLast) top2_push(t2, (uint32_t)(e + 1) < nvalid ? s[1] : __builtin_inff(), hi1);
     }
 }
 __device__ __forceinline__ void block_load(const CellBlock* blk, uint32_t b, cuint4 (&v)[4]) {
@@ -588,8 +617,9 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
     uint32_t mabs_bits = uni(meta.mabs_bits);
     uint32_t jr = 0, js = 0;
     int32_t stop = 1;  // OXHIP_STOP_ITERATIONS
-    uint64_t n_rounds = 0, n_lanes = 0, n_amb = 0, n_expand = 0, n_cut_conflict = 0, n_tie = 0, n_memo = 0, n_forced = 0, n_regrid = 0, n_steps = 0;
+    uint64_t n_rounds = 0, n_lanes = 0, n_amb = 0, n_expand = 0, n_cut_conflict = 0, n_tie = 0, n_memo = 0, n_forced = 0, n_regrid = 0, n_steps = 0, n_tail = 0, n_tail_pairs = 0;
     uint64_t t_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_pm = 0, t_c[4] = {0, 0, 0, 0}, t_cm = 0;
+    uint64_t h_lanes[8] = {0, 0, 0, 0, 0, 0, 0, 0}, h_cells[8] = {0, 0, 0, 0, 0, 0, 0, 0}, h_trips[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t t_begin = STAMP ? (uint64_t)clock64() : 0;
 #define OXHIP_CPHASE(IDX) do { if (STAMP) { const uint64_t now_ = (uint64_t)clock64(); t_ph[IDX] += now_ - t_pm; t_pm = now_; } } while (0)
     // the last whole-tree answer: valid while the tree has not grown
@@ -658,7 +688,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                         for (int k = 0; k < 3; ++k) nd[k] = lbits_f32((uint32_t)__builtin_amdgcn_readlane((int)lf32_bits(cur_nd[k]), (int)tt));
                         nd[3] = 0.0f;
                         const float sv = t + (uint32_t)u < cnt ? cell_s<DIM>(nd, tq) : __builtin_inff();   // ... so it is pushed as +inf)
-                        top2_push(ta[u], sv, i0 + tt);
+                        top2_push(ta[u], sv, (i0 + tt) << 16);
                     }
                 }
             }
@@ -725,25 +755,111 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
             constexpr int NO = DIM == 3 ? 26 : 8;
             constexpr uint8_t kOrder3[26] = {12, 14, 10, 16, 4, 22,  9, 11, 15, 17, 3, 5, 21, 23, 1, 7, 19, 25,  0, 2, 6, 8, 18, 20, 24, 26};
             constexpr uint8_t kOrder2[8] = {12, 14, 10, 16, 9, 11, 15, 17};
+            // a neighbour's box is at least sqrt(sum over its shifted axes of gap^2) away; +inf where the grid ends.  (The gaps
+            // are scaled down by 2^-20: the three roundings of a sum of squares cannot lift it above the true bound.)
+            float sq_lo[3], sq_hi[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                sq_lo[k] = (k < DIM && cq[k] > 0u) ? gap_lo[k] * gap_lo[k] : __builtin_inff();
+                sq_hi[k] = (k < DIM && cq[k] + 1u < grid.G[k]) ? gap_hi[k] * gap_hi[k] : __builtin_inff();
+            }
             auto needed = [&](float thr) -> uint32_t {
-                uint32_t mask = 0;
+                const float th = fminf(thr, 0x1.fffffep+127f);   // (no bound yet: every cell inside the grid)
+                uint32_t bits = 0;   // neighbour b ends up at bit NO - 1 - b
 #pragma unroll
                 for (int b = 0; b < NO; ++b) {
                     const int o = DIM == 3 ? kOrder3[b] : kOrder2[b];
-                    const int dx = o % 3 - 1, dy = (o / 3) % 3 - 1, dz = o / 9 - 1;
-                    const int cx = (int)cq[0] + dx, cy = (int)cq[1] + dy, cz = (int)cq[2] + dz;
-                    const float gx = dx < 0 ? gap_lo[0] : (dx > 0 ? gap_hi[0] : 0.0f), gy = dy < 0 ? gap_lo[1] : (dy > 0 ? gap_hi[1] : 0.0f);
-                    const float gz = dz < 0 ? gap_lo[2] : (dz > 0 ? gap_hi[2] : 0.0f);
-                    const bool ok = act && cx >= 0 && cx < (int)grid.G[0] && cy >= 0 && cy < (int)grid.G[1] && cz >= 0 && cz < (int)grid.G[2] &&
-                                    !(__builtin_fmaf(gx, gx, __builtin_fmaf(gy, gy, gz * gz)) > thr);
-                    mask |= ok ? (1u << b) : 0u;
+                    const int d[3] = {o % 3 - 1, (o / 3) % 3 - 1, o / 9 - 1};
+                    float l = 0.0f;
+                    bool first = true;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        if (d[k] == 0) continue;
+                        const float g2 = d[k] < 0 ? sq_lo[k] : sq_hi[k];
+                        l = first ? g2 : l + g2;
+                        first = false;
+                    }
+                    screen_bit(bits, l, th);   // !(l > th)
                 }
-                return mask;
+                const uint32_t mask = __brev(bits) >> (32 - NO);
+                return act ? mask : 0u;
             };
             uint32_t need = needed(thr2) & ~done_faces;
             // a lane's next needed cells, NB cells in flight per trip
+            uint32_t trip_no = 0;
+            // b -> (dx + 1) + 3 (dy + 1) + 9 (dz + 1) through a 5-bit-per-entry table in two 64-bit words and change
+            auto order_o = [&](uint32_t b) -> uint32_t {
+                if (DIM == 3) {
+                    constexpr uint64_t w0 = 12ull | 14ull << 5 | 10ull << 10 | 16ull << 15 | 4ull << 20 | 22ull << 25 | 9ull << 30 | 11ull << 35 | 15ull << 40 | 17ull << 45 | 3ull << 50 | 5ull << 55;
+                    constexpr uint64_t w1 = 21ull | 23ull << 5 | 1ull << 10 | 7ull << 15 | 19ull << 20 | 25ull << 25 | 0ull << 30 | 2ull << 35 | 6ull << 40 | 8ull << 45 | 18ull << 50 | 20ull << 55;
+                    constexpr uint64_t w2 = 24ull | 26ull << 5;
+                    const uint64_t w = b < 12u ? w0 : (b < 24u ? w1 : w2);
+                    const uint32_t sh5 = (b < 12u ? b : (b < 24u ? b - 12u : b - 24u)) * 5u;
+                    return (uint32_t)(w >> sh5) & 31u;
+                }
+                constexpr uint64_t w0 = 12ull | 14ull << 5 | 10ull << 10 | 16ull << 15 | 9ull << 20 | 11ull << 25 | 15ull << 30 | 17ull << 35;
+                return (uint32_t)(w0 >> (b * 5u)) & 31u;
+            };
             while (__ballot(need != 0) != 0) {
-                if (STAMP) ++n_steps;
+                if (OXHIP_CELLS_TAIL != 0 && trip_no != 0) {
+                    // THE TAIL: after a trip few lanes still ask, each for several cells -- a further trip would run every lane
+                    // through four block evaluations for their sake.  When the outstanding (query, cell) pairs fit one per
+                    // lane, they are dealt out instead: lane k evaluates pair k, the owners collect.
+                    const uint32_t cntl = (uint32_t)__popc(need);
+                    const uint32_t incl = wave_scan_u32(cntl);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                    if (total <= (uint32_t)OXHIP_CELLS_TAIL) {
+                        if (STAMP) { ++n_tail; n_tail_pairs += total; }
+                        const uint32_t first = incl - cntl;
+                        {
+                            uint32_t nd = need, pos = first;
+                            while (__ballot(nd != 0) != 0) {
+                                if (nd != 0) {
+                                    sh->tail_pair[pos & 63u] = lane | ((uint32_t)(__ffs((int)nd) - 1) << 8);
+                                    nd &= nd - 1u;
+                                    ++pos;
+                                }
+                            }
+                        }
+                        const bool mine = lane < total;
+                        const uint32_t pr = sh->tail_pair[mine ? lane : 0u];
+                        const uint32_t owner = pr & 63u;
+                        float tqo[3];
+                        uint32_t cqo[3], cco[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            tqo[k] = k < DIM ? lbits_f32((uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)lf32_bits(tq[k]))) : 0.0f;
+                            cqo[k] = k < DIM ? (uint32_t)__builtin_amdgcn_ds_bpermute((int)(owner << 2), (int)cq[k]) : 0u;
+                        }
+                        const uint32_t o = mine ? order_o(pr >> 8) : 13u;
+                        const uint32_t o3 = (o * 11u) >> 5, o9 = (o3 * 11u) >> 5;   // o / 3, o / 9 for o < 27
+                        cco[0] = cqo[0] + (o - 3u * o3) - 1u;
+                        cco[1] = cqo[1] + (o3 - 3u * o9) - 1u;
+                        cco[2] = cqo[2] + o9 - 1u;
+                        Top2 tp{__builtin_inff(), __builtin_inff(), kNoNode};
+                        cell_visit<DIM>(blk, mine ? (cco[2] * grid.G[1] + cco[1]) * grid.G[0] + cco[0] : 0u, mine, cco, tqo, tp);
+                        sh->tail_s1[lane] = tp.s1;
+                        sh->tail_s2[lane] = tp.s2;
+                        sh->tail_i1[lane] = tp.i1;
+                        for (uint32_t t = 0; __ballot(t < cntl) != 0; ++t) {
+                            const uint32_t at = (first + (t < cntl ? t : 0u)) & 63u;
+                            const float a1 = sh->tail_s1[at], a2 = sh->tail_s2[at];
+                            const uint32_t ai = sh->tail_i1[at];
+                            top2_push(t2, t < cntl ? a1 : __builtin_inff(), ai);
+                            top2_push(t2, t < cntl ? a2 : __builtin_inff(), kNoNode);
+                        }
+                        need = 0;
+                        break;
+                    }
+                }
+                if (STAMP) {
+                    ++n_steps;
+                    const uint32_t tn = trip_no < 7u ? trip_no : 7u;
+                    h_lanes[tn] += (uint64_t)__popcll(__ballot(need != 0));
+                    h_cells[tn] += wave_sum_u64((uint64_t)__popc(need));
+                    ++h_trips[tn];
+                }
+                ++trip_no;
                 constexpr int NB = OXHIP_CELLS_NB;
                 bool on[NB];
                 uint32_t cc[NB][3], cnt[NB];
@@ -753,19 +869,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                     on[t] = need != 0;
                     const uint32_t b = on[t] ? (uint32_t)(__ffs((int)need) - 1) : 0u;
                     need &= need - 1u;
-                    // b -> o through a 5-bit-per-entry table in two 64-bit words and change (registers, no memory)
-                    uint32_t o;
-                    if (DIM == 3) {
-                        constexpr uint64_t w0 = 12ull | 14ull << 5 | 10ull << 10 | 16ull << 15 | 4ull << 20 | 22ull << 25 | 9ull << 30 | 11ull << 35 | 15ull << 40 | 17ull << 45 | 3ull << 50 | 5ull << 55;
-                        constexpr uint64_t w1 = 21ull | 23ull << 5 | 1ull << 10 | 7ull << 15 | 19ull << 20 | 25ull << 25 | 0ull << 30 | 2ull << 35 | 6ull << 40 | 8ull << 45 | 18ull << 50 | 20ull << 55;
-                        constexpr uint64_t w2 = 24ull | 26ull << 5;
-                        const uint64_t w = b < 12u ? w0 : (b < 24u ? w1 : w2);
-                        const uint32_t sh5 = (b < 12u ? b : (b < 24u ? b - 12u : b - 24u)) * 5u;
-                        o = on[t] ? (uint32_t)(w >> sh5) & 31u : 13u;
-                    } else {
-                        constexpr uint64_t w0 = 12ull | 14ull << 5 | 10ull << 10 | 16ull << 15 | 9ull << 20 | 11ull << 25 | 15ull << 30 | 17ull << 35;
-                        o = on[t] ? (uint32_t)(w0 >> (b * 5u)) & 31u : 13u;
-                    }
+                    const uint32_t o = on[t] ? order_o(b) : 13u;
                     const uint32_t o3 = (o * 11u) >> 5, o9 = (o3 * 11u) >> 5;   // o / 3, o / 9 for o < 27
                     cc[t][0] = cq[0] + (o - 3u * o3) - 1u;
                     cc[t][1] = cq[1] + (o3 - 3u * o9) - 1u;
@@ -836,7 +940,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
         }
         OXHIP_CPHASE(6);   // shell searches
         // ---- the candidate in binary64, exactly as the reference computes it
-        uint32_t nearest = (act && verdict == 0) ? t2.i1 : kNoNode;
+        uint32_t nearest = (act && verdict == 0) ? t2.i1 >> 16 : kNoNode;   // (Top2::i1: the node index in the upper 16 bits)
         double q_near[D];
         {
             const uint32_t ni = nearest == kNoNode ? 0u : nearest;
@@ -1300,6 +1404,14 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
             for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&p.dbg[32 + i], (unsigned long long)t_ph[i]);
             atomicAdd((unsigned long long*)&p.dbg[13], (unsigned long long)((uint64_t)clock64() - t_begin));
             p.dbg[62] = t_c[0]; p.dbg[63] = t_c[1]; p.dbg[49] = t_c[2]; p.dbg[0] = t_c[3];
+            atomicAdd((unsigned long long*)&p.dbg[1], (unsigned long long)n_tail);
+            atomicAdd((unsigned long long*)&p.dbg[2], (unsigned long long)n_tail_pairs);
+            for (int i = 0; i < 8; ++i) {   // the neighbour trips of a round, by trip number: lanes still asking, cells asked for, trips
+                atomicAdd((unsigned long long*)&p.dbg[16 + i], (unsigned long long)h_lanes[i]);
+                atomicAdd((unsigned long long*)&p.dbg[24 + i], (unsigned long long)h_trips[i]);
+            }
+            const int ci[8] = {40, 41, 42, 43, 44, 46, 47, 48};
+            for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)&p.dbg[ci[i]], (unsigned long long)h_cells[i]);
         }
     }
 }

@@ -24,6 +24,10 @@ def show(tag, g, iters):
     print("   whole-tree events %d (ties %d), memo hits %d, shell searches %d, chain steps %d (%.1f per round), regrids %d, conflict cuts %d"
           % (int(s[4]), int(s[15]), int(s[11]), int(s[8]), int(s[9]), int(s[9]) / rounds, int(s[10]), int(s[12])))
     print("   batch-wide: whole-tree events %d, shell searches %d" % (int(s[54]), int(s[60])))
+    ci = (40, 41, 42, 43, 44, 46, 47, 48)
+    print("   neighbour trips by number (trips: lanes asking / cells asked for, per trip): " +
+          ", ".join("%d: %.1f / %.1f" % (int(s[24 + i]), int(s[16 + i]) / max(1, int(s[24 + i])), int(s[ci[i]]) / max(1, int(s[24 + i]))) for i in range(8)))
+    print("   tail passes %d, pairs per pass %.1f" % (int(s[1]), int(s[2]) / max(1, int(s[1]))))
     print("   commit split: before insert %d, insert (atomic) %d, reductions %d, checksum+rest %d per round" % tuple(int(v) // rounds for v in (s[62], s[63], s[49], s[0])))
 
 
