@@ -337,7 +337,9 @@ __device__ __forceinline__ bool cells_sample(RngWindow& rng, const DevParams& p,
 template <int DIM, bool STORE>
 __device__ __forceinline__ void cells_sample_block(RngWindow& rng, const DevParams& p, const double* goal_c, double goal_radius, uint32_t m, uint32_t lane,
                                                    CellsWaveLds<DIM>* sh, uint32_t js) {
-    const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + DIM) + 64;
+    // (exactly what cells_sample asks of the window: a fresh window of 512 words serves two rounds of 64 uniform samples in R^3
+    //  most of the time -- any slack here means ChaCha blocks computed twice)
+    const uint64_t need_hi = rng.pos + (uint64_t)m * (1 + DIM);
     if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
         rng.base_blk = uni64(rng.pos >> 3);
         uint32_t o[16];
@@ -482,6 +484,21 @@ __device__ __forceinline__ int cells_verdict(const Top2& t, double lb, double A)
     return 0;
 }
 
+// First round of part `part` when a frozen launch of `rounds` rounds is cut into `split` parts.  A part that finds its own
+// start (split <= kSelfSkipMax) pays for the rounds in front of it -- about 1 / kSkipCostInv of a round's work each -- so the
+// later parts get fewer rounds: equal finishing times need begin_p ~ (1 - (1 - c)^p) / (1 - (1 - c)^split) of the rounds.
+#ifndef OXHIP_CELLS_SKIP_COST_INV
+#define OXHIP_CELLS_SKIP_COST_INV 16
+#endif
+__host__ __device__ __forceinline__ uint32_t cells_part_begin(uint32_t rounds, uint32_t part, uint32_t split) {
+    if (part >= split) return rounds;
+    if (split > kSelfSkipMax) return (uint32_t)(((uint64_t)rounds * part) / split);
+    constexpr uint64_t ci = OXHIP_CELLS_SKIP_COST_INV;
+    uint64_t full = 1, keep_s = 1, keep_p = 1;   // ci^split, (ci - 1)^split, (ci - 1)^part ci^(split - part)
+    for (uint32_t i = 0; i < split; ++i) { full *= ci; keep_s *= ci - 1u; keep_p *= i < part ? ci - 1u : ci; }
+    return (uint32_t)(((uint64_t)rounds * (full - keep_p)) / (full - keep_s));
+}
+
 #ifndef OXHIP_CELLS_WAVES_PER_EU
 #define OXHIP_CELLS_WAVES_PER_EU 2
 #endif
@@ -581,8 +598,8 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
     uint64_t pos_start = st0.draws;
     if (split > 1) {
         const uint32_t rounds = (budget_all + 63u) / 64u;
-        j_lo = (uint32_t)(((uint64_t)rounds * part) / split) * 64u;
-        j_hi = (uint32_t)(((uint64_t)rounds * (part + 1u)) / split) * 64u;
+        j_lo = cells_part_begin(rounds, part, split) * 64u;
+        j_hi = cells_part_begin(rounds, part + 1u, split) * 64u;
         if (j_hi > budget_all) j_hi = budget_all;
         if (split > kSelfSkipMax) pos_start = p.cell_part_pos[(size_t)prob * kMaxSplit + part];   // (else: found below)
     }
@@ -1449,7 +1466,7 @@ __global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
     const uint32_t budget = (uint32_t)p.budget, rounds = (budget + 63u) / 64u;
     uint32_t next_part = 0;
     for (uint32_t r = 0; r < rounds; ++r) {
-        while (next_part < split && (uint32_t)(((uint64_t)rounds * next_part) / split) == r) {
+        while (next_part < split && cells_part_begin(rounds, next_part, split) == r) {
             if (lane == 0) p.cell_part_pos[(size_t)prob * kMaxSplit + next_part] = rng.pos;
             ++next_part;
         }
