@@ -35,7 +35,7 @@
 namespace oxhip {
 
 #ifndef OXHIP_CELLS_BRUTE
-#define OXHIP_CELLS_BRUTE 1024
+#define OXHIP_CELLS_BRUTE 512
 #endif
 constexpr uint32_t kBruteMax = OXHIP_CELLS_BRUTE;   // trees up to this size: every node, by index
 constexpr uint32_t kFlatCap = 4096;                  // entries of a problem's flat list (oxhip_api.hip allocates them)
@@ -46,6 +46,9 @@ constexpr uint32_t kMaxSplit = 64;                   // parts a frozen launch of
 constexpr int kMaxShell = 6;                         // the cooperative search gives up beyond this ring (-> whole-tree path)
 #ifndef OXHIP_CELLS_NB
 #define OXHIP_CELLS_NB 4                             // neighbour cells in flight per trip
+#endif
+#ifndef OXHIP_CELLS_WT_UNROLL
+#define OXHIP_CELLS_WT_UNROLL 4
 #endif
 #ifndef OXHIP_CELLS_TAIL
 #define OXHIP_CELLS_TAIL 64                          // at most this many outstanding (query, cell) pairs: one pair per lane (0: off)
@@ -1242,22 +1245,23 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
             if (!same_q) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this wave's stores to the tree have landed (same CU)
                 Scan ps{__builtin_inf(), kNoNode, 0xFFFFFFFFu};  // .slot is used as the node index here
-                for (uint32_t i0 = 4u * lane; i0 < n; i0 += 1024u) {
-                    uint32_t sk4[4], il[4];
-                    double d16[4][4];
+                constexpr int WT = OXHIP_CELLS_WT_UNROLL;   // chunks of 256 nodes in flight (4 nodes per lane each)
+                for (uint32_t i0 = 4u * lane; i0 < n; i0 += 256u * (uint32_t)WT) {
+                    uint32_t sk4[WT], il[WT];
+                    double d16[WT][4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < WT; ++t) {
                         const uint32_t ib = i0 + 256u * (uint32_t)t;
                         il[t] = ib < n ? ib : 0u;   // (rows are padded to cap >= n rounded up to 1024)
                         sk4[t] = *reinterpret_cast<const uint32_t*>(skip + il[t]);
                     }
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
-                        ldouble4 ck[4];
+                        ldouble4 ck[WT];
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) ck[t] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il[t]);
+                        for (int t = 0; t < WT; ++t) ck[t] = *reinterpret_cast<const ldouble4*>(tree + (size_t)k * cap + il[t]);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
+                        for (int t = 0; t < WT; ++t) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const double df = ck[t][r] - q1[k];
@@ -1267,7 +1271,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < WT; ++t) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const uint32_t i = i0 + 256u * (uint32_t)t + (uint32_t)r;
