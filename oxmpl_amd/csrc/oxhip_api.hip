@@ -35,7 +35,7 @@ struct oxhip_rrt_batch {
     DevBuf<double> cell_xyz;
     DevBuf<CellMeta> cell_meta;
     DevBuf<CellAcc> cell_acc;
-    DevBuf<uint64_t> cell_part_pos;
+    DevBuf<uint64_t> cell_part_pos, sph_grid;
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
@@ -301,6 +301,8 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         if (e2 == hipSuccess) e2 = b->cell_meta.alloc(P);
         if (e2 == hipSuccess) e2 = b->cell_acc.alloc(P);
         if (e2 == hipSuccess) e2 = b->cell_part_pos.alloc((size_t)P * 64);
+        dp.sph_grid_G = sphere_grid_side(dim);
+        if (e2 == hipSuccess) e2 = b->sph_grid.alloc(dim == 2 ? (size_t)dp.sph_grid_G * dp.sph_grid_G : (size_t)dp.sph_grid_G * dp.sph_grid_G * dp.sph_grid_G);
         if (e2 == hipSuccess) e2 = hipMemset(b->cell_meta.p, 0, (size_t)P * sizeof(CellMeta));
         if (e2 == hipSuccess) e2 = hipMemset(b->cell_acc.p, 0, (size_t)P * sizeof(CellAcc));
         if (e2 != hipSuccess) {
@@ -309,7 +311,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             return fail(OXHIP_ERR_HIP, msg);
         }
         dp.cell_blk = b->cell_blk.p; dp.cell_flat = b->cell_flat.p; dp.cell_xyz = b->cell_xyz.p; dp.cell_meta = b->cell_meta.p;
-        dp.cell_acc = b->cell_acc.p; dp.cell_part_pos = b->cell_part_pos.p;
+        dp.cell_acc = b->cell_acc.p; dp.cell_part_pos = b->cell_part_pos.p; dp.sph_grid = b->sph_grid.p;
     }
     if (kind == OXHIP_KERNEL_LANES && !lanes_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
@@ -495,6 +497,7 @@ static int32_t refresh_filter(oxhip_rrt_batch* b) {
     int32_t st = upload(b->sph_filt, f, b->stream);
     if (st != OXHIP_OK) return st;
     b->dp.sph_filt = b->sph_filt.p;
+    if (b->sph_grid.p && n > 0) launch_sphere_grid(b->dp, b->sph_grid.p, b->stream);   // (rrt_cells.hip looks the midpoint filter up)
     if (b->star_wired) {   // motion_seq.hpp filters motions of any length: it takes the radii as given and this absolute margin
         if ((st = upload(b->sph_r, b->sph_radii, b->stream)) != OXHIP_OK) return st;
         b->dp.sph_r = b->sph_r.p;

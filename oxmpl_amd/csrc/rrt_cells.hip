@@ -47,6 +47,9 @@ constexpr int kMaxShell = 6;                         // the cooperative search g
 #ifndef OXHIP_CELLS_NB
 #define OXHIP_CELLS_NB 4                             // neighbour cells in flight per trip
 #endif
+#ifndef OXHIP_ABLATE
+#define OXHIP_ABLATE 0   // (timing experiments only: 1 no sphere pre-filter, 2 no neighbour cells, 4 no motion check, 8 first trip without faces)
+#endif
 #ifndef OXHIP_CELLS_WT_UNROLL
 #define OXHIP_CELLS_WT_UNROLL 4
 #endif
@@ -74,7 +77,6 @@ struct CellsWaveLds {
     uint64_t pos_after[64];
     double newn[DIM][64];         // the round's would-be new nodes, by rank
     float newn32[64][4];          // ... as the dot-product pre-screen holds them: fl32(x - c0), fl32(|.|^2)
-    float obs32_thr[64];          // the sphere pre-filter's thresholds (they carry this problem's magnitude bound)
     uint32_t tail_pair[64];       // the tail pass: (owner lane | neighbour number << 8) of the k-th outstanding (query, cell) pair ...
     float tail_s1[64], tail_s2[64];   // ... and what lane k found in that cell
     uint32_t tail_i1[64];
@@ -82,7 +84,6 @@ struct CellsWaveLds {
 template <int DIM>
 struct CellsShared {
     double obs[DIM + 2][64];      // first 64 spheres: centre, validity threshold, filter threshold
-    float obs32[64][4];           // fl32(centre - c0), fl32(|.|^2)
     CellsWaveLds<DIM> w[kCellsWaves];
 };
 
@@ -557,30 +558,18 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
         const double u = 0x1p-24;
         mg.usable = h < 1e15 && fabs(c0[0]) < 1e300;
         mg.e2 = 2.0 * (u * h * h * (double)(D * (3 * D + 9)) * 1.0001 + 1e-290);
-        // the spheres for the binary32 pre-filter of the motion check: same error model with H_f = max(H, |centre - c0|)
-        double hs = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) hs = fmax(hs, lane < ns64 ? fabs(oc[k] - c0[k]) : 0.0);
-        const double hf = fmax(h, wave_max_f64pos(hs));
-        const double ef = 2.0 * (u * hf * hf * (double)(D * (3 * D + 9)) * 1.0001 + 1e-290);
-        if (wave == 0) {
-            double sq = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                const float f = (float)(oc[k] - c0[k]);
-                shared.obs32[lane][k] = f;
-                sq += (double)f * (double)f;
-            }
-            shared.obs32[lane][D] = (float)sq;
-        }
-        // a sphere is cleared when s' + |m|^2 > thr: thr = (filter threshold + 2 E_f), rounded up (and two ulps more for the sum)
-        float thr = (float)((ofilt + ef) * (1.0 + 0x1p-21));
-        thr = thr + fabsf(thr) * 0x1p-22f;
-        sh->obs32_thr[lane] = (lane < ns64 && mg.usable && hf < 1e15 && ofilt >= 0.0) ? thr : (lane < ns64 ? __builtin_inff() : -1.0f);
     }
     __syncthreads();   // the launch's only barrier: the obstacle tables are in LDS
     if (!live) return;
     if (p.stop_at_goal && st0.goal_node >= 0) return;
+    // the midpoint filter's lookup (DevParams::sph_grid): cell = (mid - lo) G / (hi - lo), from fl32(mid - c0)
+    float sg_inv[D], sg_bias[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double inv = (double)p.sph_grid_G / (p.hi[k] - p.lo[k]);
+        sg_inv[k] = lbits_f32(uni(lf32_bits((float)inv)));
+        sg_bias[k] = lbits_f32(uni(lf32_bits((float)((c0[k] - p.lo[k]) * inv))));
+    }
 
     const size_t cap = p.cap;
     double* tree = p.tree + (size_t)prob * DIM * cap;
@@ -804,7 +793,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                 const uint32_t mask = __brev(bits) >> (32 - NO);
                 return act ? mask : 0u;
             };
-            uint32_t need = needed(thr2) & ~done_faces;
+            uint32_t need = (OXHIP_ABLATE & 2) ? 0u : needed(thr2) & ~done_faces;
             // a lane's next needed cells, NB cells in flight per trip
             uint32_t trip_no = 0;
             // b -> (dx + 1) + 3 (dy + 1) + 9 (dz + 1) through a 5-bit-per-entry table in two 64-bit words and change
@@ -1000,32 +989,25 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
         bool bad = false;
         if (nobs > 0) {
             lerp<DIM>(q_near, qn, 0.5, mid, DIM);
-            float Qm[D], mm = 0.0f;
+            // ... looked up: the grid cell of the midpoint holds the spheres whose filter ball reaches the cell (a superset of
+            // the spheres the midpoint test keeps; the cells are built 2^-9 wider than they are, the index below is good to
+            // 2^-17 cells).  A midpoint outside the bounds (a tree handed in from outside) takes every sphere.
+            uint64_t cand;
             {
-                double mmd = 0.0;
+                const float gs = (float)p.sph_grid_G;
+                bool inside = mg.usable && !(OXHIP_ABLATE & 1);
+                uint32_t ci[3] = {0u, 0u, 0u};
 #pragma unroll
                 for (int k = 0; k < D; ++k) {
-                    const float mk = (float)(mid[k] - c0[k]);
-                    Qm[k] = -2.0f * mk;
-                    mmd += (double)mk * (double)mk;
+                    const float u = __builtin_fmaf((float)(mid[k] - c0[k]), sg_inv[k], sg_bias[k]);
+                    inside = inside && u >= -0x1p-10f && u <= gs + 0x1p-10f;   // (NaN: outside)
+                    const float fl = floorf(u);
+                    ci[k] = fl > 0.0f ? (fl < gs ? (uint32_t)fl : p.sph_grid_G - 1u) : 0u;
                 }
-                mm = (float)(mmd * (1.0 - 0x1p-22));   // rounded down: errs towards "maybe"
+                const uint64_t m = p.sph_grid[D == 3 ? (ci[2] * p.sph_grid_G + ci[1]) * p.sph_grid_G + ci[0] : ci[1] * p.sph_grid_G + ci[0]];
+                cand = inside ? m : ~0ull;
             }
-            uint32_t maybe_lo = 0, maybe_hi = 0;
-            for (uint32_t o0 = 0; o0 < ns64; o0 += 8) {
-                uint32_t b8 = 0;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float* of = shared.obs32[o0 + t];
-                    float sp = of[D];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) sp = __builtin_fmaf(of[k], Qm[k], sp);
-                    screen_bit(b8, sp + mm, sh->obs32_thr[o0 + t]);   // !(sp + mm > thr)  (NaN / inf threshold: maybe; -1: no sphere)
-                }
-                const uint32_t bits = rev8(b8);
-                if (o0 < 32) maybe_lo |= bits << o0; else maybe_hi |= bits << (o0 - 32);
-            }
-            if (!mg.usable) { maybe_lo = 0xFFFFFFFFu; maybe_hi = 0xFFFFFFFFu; }
+            uint32_t maybe_lo = (uint32_t)cand, maybe_hi = (uint32_t)(cand >> 32);
             {
                 uint64_t rem = ((uint64_t)maybe_hi << 32) | maybe_lo;
                 if (ns64 < 64) rem &= (1ull << ns64) - 1ull;
@@ -1044,7 +1026,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
             }
             const uint64_t maybe = ((uint64_t)maybe_hi << 32) | maybe_lo;
             OXHIP_CPHASE(2);   // sphere filter
-            const bool need = act && !amb && (maybe != 0 || extras);
+            const bool need = !(OXHIP_ABLATE & 4) && act && !amb && (maybe != 0 || extras);
             if (__ballot(need) != 0) {
                 // ... and every lane steps through its own motion against just those (is_valid is pure: testing all states
                 // equals the reference's first-invalid early exit)
@@ -1482,6 +1464,35 @@ __global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
         if (lane == 0) p.cell_part_pos[(size_t)prob * kMaxSplit + next_part] = rng.pos;
         ++next_part;
     }
+}
+
+// DevParams::sph_grid: one thread per cell of the bounds' grid; bit j = sphere j's filter ball (every midpoint within sqrt(sph_filt)
+// of the centre) reaches the cell's box, taken 2^-9 of a cell wider on every side.  (NaN / +inf thresholds: always set.)
+__global__ __launch_bounds__(256) void sphere_grid_kernel(DevParams p, uint64_t* grid) {
+    const uint32_t G = p.sph_grid_G, dim = p.dim;
+    const uint32_t cells = dim == 2 ? G * G : G * G * G;
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= cells) return;
+    const uint32_t ic[3] = {idx % G, (idx / G) % G, idx / (G * G)};
+    const uint32_t ns64 = p.n_spheres < 64 ? p.n_spheres : 64;
+    uint64_t mask = 0;
+    for (uint32_t j = 0; j < ns64; ++j) {
+        double d2 = 0.0;
+        for (uint32_t k = 0; k < dim; ++k) {
+            const double w = (p.hi[k] - p.lo[k]) / (double)G;
+            const double blo = p.lo[k] + ((double)ic[k] - 0x1p-9) * w, bhi = p.lo[k] + ((double)ic[k] + 1.0 + 0x1p-9) * w;
+            const double c = p.sph_c[(size_t)k * p.n_spheres + j];
+            const double e = fmax(fmax(blo - c, c - bhi), 0.0);
+            d2 += e * e;
+        }
+        if (!(d2 * (1.0 - 1e-9) > p.sph_filt[j])) mask |= 1ull << j;
+    }
+    grid[idx] = mask;
+}
+uint32_t sphere_grid_side(uint32_t dim) { return dim == 2 ? 128u : 32u; }
+void launch_sphere_grid(const DevParams& p, uint64_t* grid, hipStream_t stream) {
+    const uint32_t G = p.sph_grid_G, cells = p.dim == 2 ? G * G : G * G * G;
+    hipLaunchKernelGGL(sphere_grid_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, stream, p, grid);
 }
 
 bool cells_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && cap <= 65535u; }   // (a block entry names its node with 16 bits)

@@ -146,6 +146,10 @@ struct DevParams {
     CellAcc* cell_acc;       // [P] zero between launches
     uint64_t* cell_part_pos; // [P][8] stream position at which each part of a split frozen launch starts
     uint32_t cell_blocks, cell_level_max, cells_split;
+    // the spheres a motion's midpoint can meet, looked up instead of screened: bit j of sph_grid[cell] is set when sphere j's filter
+    // ball (sph_filt) reaches the cell's box (sph_grid_G cells along every axis of the bounds, dimensions 2 / 3)
+    const uint64_t* sph_grid;
+    uint32_t sph_grid_G;
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
