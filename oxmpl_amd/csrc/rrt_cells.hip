@@ -974,7 +974,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
         const uint32_t hb = hi32(g) + 1;
         double qn[D], mid[D];
         steer<DIM>(p, false, g, q_near, q, qn);
-        const bool dup = g == 0.0;
+        bool dup = g == 0.0;
         OXHIP_CPHASE(1);   // candidate + steer
         // this lane's query as the dot-product pre-screens see it: Q = -2 fl32(q - c0), |b|^2
         float Qf[D];
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
             }
         }
         OXHIP_CPHASE(3);   // motion check
-        const bool ok = act && !bad;
+        bool ok = act && !bad;
         constexpr bool ins = !FROZEN;
         float nf_a[D], nf_cc;
         {
@@ -1078,36 +1078,30 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
         int32_t stop_after = -1;
         const uint64_t ambm = __ballot(amb);
         if (ambm != 0) cut = (uint32_t)(__ffsll((unsigned long long)ambm) - 1);
-        const uint64_t okm = __ballot(ok);
+        const uint32_t amb_at = cut;   // lanes [0, amb_at) hold a proven nearest node of the tree as it was when the round began
+        uint64_t okm = __ballot(ok);
         uint64_t hitm = 0;
         if (ins) {
-            // node cap: query j is processed only while the tree has room (checked before any draw of the iteration)
-            const uint64_t capm = __ballot(act && n + (uint32_t)__popcll(okm & below_mask(lane)) >= p.max_nodes);
-            if (capm != 0) {
-                const uint32_t c = (uint32_t)(__ffsll((unsigned long long)capm) - 1);
-                if (c <= cut) { cut = c; stop_after = 2; }
-            }
-            hitm = __ballot(ok && dist2<D>(qn, goal_c, DIM) <= goal_thr);
-            if (p.stop_at_goal && hitm != 0) {
-                const uint32_t c = (uint32_t)__ffsll((unsigned long long)hitm);   // first hit lane + 1
-                if (c <= cut) { cut = c; stop_after = 0; }
-            }
-            // a node accepted earlier in the round that is (nearly) as close to a later query as that query's nearest node
-            // changes that query's result: the prefix ends before the first such query (binary32 first: the new node of lane i
-            // matters to lane j only if d2 <= g_j (1 + 2^-19)).  The would-be new nodes are staged by rank.
-            const uint64_t newm = __ballot(ok && !dup);
-            const uint32_t rank = (uint32_t)__popcll(newm & below_mask(lane));
+            // A node accepted earlier in the round that is (nearly) as close to a later query as that query's nearest node changes
+            // that query's result.  Such a query is REPAIRED in place: its nearest node is then the old one or one of those few
+            // new nodes -- the reference's loop (rrt.rs:187-196: sqrt, strict '<', ascending index) over just them, the steer and
+            // the motion check by the whole wave -- and the queries behind it are tested against its new node.  The would-be new
+            // nodes are staged by lane; bit i of `confl` = the staged node of lane i < lane matters to this lane's query (binary32
+            // first: d2 <= g (1 + 2^-19) is possible; then the binary64 value within a rounding of g).
+            bool hit = ok && dist2<D>(qn, goal_c, DIM) <= goal_thr;
+            uint64_t newm = __ballot(ok && !dup && lane < amb_at);
             const float thr_c = (mg.usable && g < 1e300) ? f32_up(g * (1.0 + 0x1p-19) - bb + mg.e2) : __builtin_inff();
             if (ok && !dup) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) { sh->newn32[rank][k] = nf_a[k]; sh->newn[k][rank] = qn[k]; }
-                sh->newn32[rank][D] = nf_cc;
+                for (int k = 0; k < D; ++k) { sh->newn32[lane][k] = nf_a[k]; sh->newn[k][lane] = qn[k]; }
+                sh->newn32[lane][D] = nf_cc;
             }
-            const uint32_t n_new = (uint32_t)__popcll(newm);
-            for (uint32_t t0 = 0; t0 < n_new; t0 += 8) {
-                const uint32_t ahead = rank < n_new ? rank : n_new;
-                const uint32_t t_hi = ahead > t0 ? (ahead - t0 < 8u ? ahead - t0 : 8u) : 0u;
-                const uint32_t valid = (act && lane < cut) ? ((1u << t_hi) - 1u) : 0u;
+            uint64_t confl = 0;
+            for (uint32_t t0 = 0; t0 + 1u < amb_at; t0 += 8) {
+                const uint32_t grp = (uint32_t)(newm >> t0) & 0xFFu;   // (uniform)
+                if (grp == 0) continue;
+                const uint32_t ahead = lane > t0 ? (lane - t0 < 8u ? lane - t0 : 8u) : 0u;   // staged slots of this group in front of the lane
+                const uint32_t valid = (act && lane < amb_at) ? (grp & ((1u << ahead) - 1u)) : 0u;
                 uint32_t bits = 0;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
@@ -1126,16 +1120,97 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                             double ca[D];
 #pragma unroll
                             for (int k = 0; k < D; ++k) ca[k] = sh->newn[k][sl];
-                            const uint64_t cm = __ballot(((lookm >> t) & 1u) != 0 && hi32(dist2<D>(ca, q, DIM)) <= hb);
-                            if (cm != 0) {
-                                const uint32_t c = (uint32_t)(__ffsll((unsigned long long)cm) - 1);
-                                if (c < cut) { cut = c; stop_after = -1; if (STAMP) ++n_cut_conflict; }
-                            }
+                            if (((lookm >> t) & 1u) != 0 && hi32(dist2<D>(ca, q, DIM)) <= hb) confl |= 1ull << sl;
                         }
                     }
                 }
-                const uint64_t behind = newm & ~first_n_mask(cut);
-                if (t0 + 8 >= n_new - (uint32_t)__popcll(behind)) break;
+            }
+            while (true) {
+                const uint64_t dirtym = __ballot((confl & newm) != 0);   // (bits at or beyond a lane, or of lanes past amb_at, are never set)
+                if (dirtym == 0) break;
+                const uint32_t c = (uint32_t)(__ffsll((unsigned long long)dirtym) - 1);
+                if (STAMP) ++n_cut_conflict;
+                const uint64_t candm = uni64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((confl & newm) >> 32), (int)c) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(confl & newm), (int)c));
+                double qc[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) qc[k] = unid(sh->q[k][(jr + c) & 63u]);
+                double best_d = sqrt(readlane_f64(g, (int)c));   // the old nearest node: the lowest index, so it keeps every tie
+                uint32_t best = 64u;
+                for (uint64_t rem = candm; rem != 0; rem &= rem - 1) {
+                    const uint32_t i = (uint32_t)(__ffsll((unsigned long long)rem) - 1);
+                    double ca[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) ca[k] = unid(sh->newn[k][i]);
+                    const double d = sqrt(dist2<D>(ca, qc, DIM));
+                    if (d < best_d) { best_d = d; best = i; }
+                }
+                if (best != 64u) {   // a node of this round is the query's nearest: everything that follows from it, again
+                    double q_near1[D], qn1[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) q_near1[k] = unid(sh->newn[k][best]);
+                    const uint32_t nearest1 = n + (uint32_t)__popcll(okm & below_mask(best));
+                    const double g1 = dist2<D>(q_near1, qc, DIM);
+                    steer<DIM>(p, false, g1, q_near1, qc, qn1);
+                    bool ok1 = true;
+                    if (nobs > 0) {
+                        double mid1[D];
+                        lerp<DIM>(q_near1, qn1, 0.5, mid1, DIM);
+                        if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid1)) != 0 || extras)
+                            ok1 = motion_lanes<DIM>(p, lane, q_near1, qn1, oc, othr, ofilt, ns64);
+                    }
+                    const bool dup1 = g1 == 0.0;
+                    const bool hit1 = ok1 && dist2<D>(qn1, goal_c, DIM) <= goal_thr;
+                    float na1[D], ncc1;
+                    {
+                        double sq = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            na1[k] = (float)(qn1[k] - c0[k]);
+                            sq += (double)na1[k] * (double)na1[k];
+                        }
+                        ncc1 = (float)sq;
+                    }
+                    if (lane == c) {
+                        nearest = nearest1;
+                        g = g1;
+                        ok = ok1;
+                        dup = dup1;
+                        hit = hit1;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) { qn[k] = qn1[k]; q_near[k] = q_near1[k]; nf_a[k] = na1[k]; }
+                        nf_cc = ncc1;
+                        if (ok1 && !dup1) {
+#pragma unroll
+                            for (int k = 0; k < D; ++k) { sh->newn32[c][k] = na1[k]; sh->newn[k][c] = qn1[k]; }
+                            sh->newn32[c][D] = ncc1;
+                        }
+                    }
+                    const uint64_t bitc = 1ull << c;
+                    okm = ok1 ? (okm | bitc) : (okm & ~bitc);
+                    newm = (ok1 && !dup1) ? (newm | bitc) : (newm & ~bitc);
+                    // the queries behind it against its new node
+                    confl &= ~bitc;
+                    if (ok1 && !dup1) {
+                        float sp = ncc1;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) sp = __builtin_fmaf(na1[k], Qf[k], sp);
+                        const bool look = act && lane > c && lane < amb_at && !(sp > thr_c);
+                        if (look && hi32(dist2<D>(qn1, q, DIM)) <= hb) confl |= bitc;
+                    }
+                }
+                if (lane == c) confl = 0;
+            }
+            hitm = __ballot(hit);
+            // node cap: query j is processed only while the tree has room (checked before any draw of the iteration)
+            const uint64_t capm = __ballot(act && n + (uint32_t)__popcll(okm & below_mask(lane)) >= p.max_nodes);
+            if (capm != 0) {
+                const uint32_t c = (uint32_t)(__ffsll((unsigned long long)capm) - 1);
+                if (c <= cut) { cut = c; stop_after = 2; }
+            }
+            if (p.stop_at_goal && hitm != 0) {
+                const uint32_t c = (uint32_t)__ffsll((unsigned long long)hitm);   // first hit lane + 1
+                if (c <= cut) { cut = c; stop_after = 0; }
             }
         }
         if ((p.dbg_flags & OXHIP_DEBUG_ONE_LANE_ROUNDS) != 0 && cut > 1) { cut = 1; stop_after = -1; if (STAMP) ++n_forced; }
