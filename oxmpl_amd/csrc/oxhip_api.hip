@@ -291,9 +291,9 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         // head blocks for the finest grid this capacity reaches + the overflow blocks (n nodes overflow into at most n / 7)
         dp.cell_blocks = cells_head_blocks(dim, cap) + cap / 7u + 64u;
         // frozen launches: a problem's iterations are independent, so they are divided over enough waves to fill the chip
-        // (256 CUs x 8 waves of this kernel's register budget)
+        // (256 CUs x 12 waves of the frozen specialisation's register budget)
         uint32_t split = cfg->frozen_split;
-        if (split == 0) { split = (2048u + P - 1u) / P; if (split > 8u) split = 8u; if (split < 1u) split = 1u; }
+        if (split == 0) { split = (3072u + P - 1u) / P; if (split > 8u) split = 8u; if (split < 1u) split = 1u; }
         dp.cells_split = split;
         hipError_t e2 = b->cell_blk.alloc((size_t)P * dp.cell_blocks);
         if (e2 == hipSuccess) e2 = b->cell_flat.alloc((size_t)P * 4096 * 4);

@@ -53,6 +53,9 @@ constexpr int kMaxShell = 6;                         // the cooperative search g
 #ifndef OXHIP_CELLS_WT_UNROLL
 #define OXHIP_CELLS_WT_UNROLL 4
 #endif
+#ifndef OXHIP_CELLS_NB_FROZEN
+#define OXHIP_CELLS_NB_FROZEN 3                      // ... of a frozen launch (three waves per SIMD hide the latency; 16 registers per cell in flight)
+#endif
 #ifndef OXHIP_CELLS_TAIL
 #define OXHIP_CELLS_TAIL 64                          // at most this many outstanding (query, cell) pairs: one pair per lane (0: off)
 #endif
@@ -507,7 +510,7 @@ __host__ __device__ __forceinline__ uint32_t cells_part_begin(uint32_t rounds, u
 #define OXHIP_CELLS_WAVES_PER_EU 2
 #endif
 #ifndef OXHIP_CELLS_WAVES_PER_EU_FROZEN
-#define OXHIP_CELLS_WAVES_PER_EU_FROZEN 2   // the frozen specialisation (no insert, no prefix) of a steady-state launch
+#define OXHIP_CELLS_WAVES_PER_EU_FROZEN 3   // the frozen specialisation (no insert, no prefix code) of a steady-state launch: 168 registers
 #endif
 template <int DIM, bool STAMP, bool FROZEN>
 __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU_FROZEN : OXHIP_CELLS_WAVES_PER_EU) void rrt_cells_kernel(DevParams p) {
@@ -528,17 +531,13 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
     double c0[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) c0[k] = 0.5 * p.lo[k] + 0.5 * p.hi[k];
-    // sphere `lane`: registers (the wave-wide motion check of the whole-tree path) and LDS (the lane-parallel checks)
-    double oc[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) oc[k] = lane < ns64 ? p.sph_c[(size_t)k * p.n_spheres + lane] : 0.0;
-    const double othr = lane < ns64 ? p.sph_thr[lane] : -1.0;
-    const double ofilt = lane < ns64 ? p.sph_filt[lane] : -1.0;
+    // sphere `lane` in LDS: the lane-parallel checks read any sphere, the wave-wide motion check (whole-tree path, repairs) reads
+    // its own lane's back into registers when it runs (not held across the rounds: ten registers)
     if (wave == 0) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) shared.obs[k][lane] = oc[k];
-        shared.obs[D][lane] = othr;
-        shared.obs[D + 1][lane] = ofilt;
+        for (int k = 0; k < D; ++k) shared.obs[k][lane] = lane < ns64 ? p.sph_c[(size_t)k * p.n_spheres + lane] : 0.0;
+        shared.obs[D][lane] = lane < ns64 ? p.sph_thr[lane] : -1.0;
+        shared.obs[D + 1][lane] = lane < ns64 ? p.sph_filt[lane] : -1.0;
     }
     const bool live = prob < p.n_problems;
     const ProblemState st0 = p.state[live ? prob : 0u];
@@ -869,7 +868,7 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                     ++h_trips[tn];
                 }
                 ++trip_no;
-                constexpr int NB = OXHIP_CELLS_NB;
+                constexpr int NB = FROZEN ? OXHIP_CELLS_NB_FROZEN : OXHIP_CELLS_NB;
                 bool on[NB];
                 uint32_t cc[NB][3], cnt[NB];
                 cuint4 v[NB][4];
@@ -1156,6 +1155,10 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                     if (nobs > 0) {
                         double mid1[D];
                         lerp<DIM>(q_near1, qn1, 0.5, mid1, DIM);
+                        double oc[D];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) oc[k] = shared.obs[k][lane];
+                        const double othr = shared.obs[D][lane], ofilt = shared.obs[D + 1][lane];
                         if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid1)) != 0 || extras)
                             ok1 = motion_lanes<DIM>(p, lane, q_near1, qn1, oc, othr, ofilt, ns64);
                     }
@@ -1382,6 +1385,10 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
             if (nobs > 0) {
                 double mid1[D];
                 lerp<DIM>(q_near1, qn1, 0.5, mid1, DIM);
+                double oc[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) oc[k] = shared.obs[k][lane];
+                const double othr = shared.obs[D][lane], ofilt = shared.obs[D + 1][lane];
                 if (__ballot(sphere_maybe_hit<DIM>(oc, ofilt, mid1)) != 0 || extras)
                     ok1 = motion_lanes<DIM>(p, lane, q_near1, qn1, oc, othr, ofilt, ns64);
             }

@@ -9,7 +9,7 @@ from oxmpl_amd import capi, scenarios  # noqa: E402
 
 sc = scenarios.config2()
 P = 1024
-splits = [int(a) for a in sys.argv[1:]] or [2]
+splits = [int(a) for a in sys.argv[1:]] or [0]
 ref = scenarios.make_batch(sc, P, 10000, False, 42, 0, 0, capi.KERNEL_LANES)
 ref.solve(10 ** 7)
 rc = ref.counts()
