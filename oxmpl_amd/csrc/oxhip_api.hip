@@ -36,6 +36,7 @@ struct oxhip_rrt_batch {
     DevBuf<CellMeta> cell_meta;
     DevBuf<CellAcc> cell_acc;
     DevBuf<uint64_t> cell_part_pos, sph_grid;
+    ProblemState* h_states = nullptr;   // pinned: the state array as the host reads it after every launch
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
@@ -350,6 +351,7 @@ int32_t oxhip_rrt_batch_destroy(oxhip_rrt_batch* b) {
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->h_states) (void)hipHostFree(b->h_states);
     delete b;
     return OXHIP_OK;
 }
@@ -450,6 +452,7 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
     HIP_TRY(hipMemsetAsync(b->skip.p, 0, (size_t)P * cap, b->stream));
     if (b->shadow_state.p) HIP_TRY(hipMemsetAsync(b->shadow_state.p, 0, (size_t)P * 2 * sizeof(uint32_t), b->stream));  // shadows start over
     if (b->cell_meta.p) HIP_TRY(hipMemsetAsync(b->cell_meta.p, 0, (size_t)P * sizeof(CellMeta), b->stream));              // the grids too
+    b->dp.cells_meta_ok = 0;
     std::vector<int32_t> minus1(P, -1);
     HIP_TRY(hipMemcpy2DAsync(b->parent.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
                              sizeof(int32_t), P, hipMemcpyHostToDevice, b->stream));
@@ -556,6 +559,7 @@ int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const dou
     if (b->shadow_state.p)   // this problem's fl32 shadow starts over
         HIP_TRY(hipMemsetAsync(b->shadow_state.p + 2 * (size_t)problem, 0, 2 * sizeof(uint32_t), b->stream));
     if (b->cell_meta.p) HIP_TRY(hipMemsetAsync(b->cell_meta.p + problem, 0, sizeof(CellMeta), b->stream));   // ... and its cell grid
+    b->dp.cells_meta_ok = 0;
     std::vector<ProblemState> states;
     if ((st = read_states(b, states)) != OXHIP_OK) return st;
     states[problem].n_nodes = n;
@@ -566,8 +570,10 @@ int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const dou
 
 static int32_t read_states(oxhip_rrt_batch* b, std::vector<ProblemState>& states) {
     states.resize(b->cfg.n_problems);
-    HIP_TRY(hipMemcpyAsync(states.data(), b->state.p, states.size() * sizeof(ProblemState), hipMemcpyDeviceToHost, b->stream));
+    if (!b->h_states) HIP_TRY(hipHostMalloc((void**)&b->h_states, states.size() * sizeof(ProblemState), hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(b->h_states, b->state.p, states.size() * sizeof(ProblemState), hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+    std::memcpy(states.data(), b->h_states, states.size() * sizeof(ProblemState));
     return OXHIP_OK;
 }
 
@@ -671,25 +677,24 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT) launch_rrt_connect(b->dp, b->stream);
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR && b->star_wired) {
             // geometry: exactly RRT's loop on the same stream (rrt_star_wire.hip's header); then wire the new nodes
-            if (b->star_geo_cells) launch_rrt_cells(b->dp, b->stream); else launch_rrt_lanes(b->dp, b->stream);
+            if (b->star_geo_cells) { launch_rrt_cells(b->dp, b->stream); b->dp.cells_meta_ok = 1; } else launch_rrt_lanes(b->dp, b->stream);
             HIP_TRY(hipGetLastError());
             if ((st = wire_new_nodes(b)) != OXHIP_OK) return st;
         }
         else if (b->cfg.planner == OXHIP_PLANNER_RRT_STAR) launch_rrt_star(b->dp, b->stream);
-        else if (kind == OXHIP_KERNEL_CELLS) launch_rrt_cells(b->dp, b->stream);
+        else if (kind == OXHIP_KERNEL_CELLS) { launch_rrt_cells(b->dp, b->stream); b->dp.cells_meta_ok = 1; }
         else if (kind == OXHIP_KERNEL_LANES) launch_rrt_lanes(b->dp, b->stream);
         else if (kind == OXHIP_KERNEL_RESIDENT) launch_rrt_resident(b->dp, b->stream);
         else launch_rrt_stream(b->dp, b->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(b->ev1, b->stream));
-        HIP_TRY(hipStreamSynchronize(b->stream));
+        if ((st = read_states(b, states)) != OXHIP_OK) return st;   // (the launch's one synchronisation: the stop reasons come with it)
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, b->ev0, b->ev1));
         b->last_kernel_ms += ms;
         b->last_launches++;
         remaining -= step;
         if (remaining == 0) break;
-        if ((st = read_states(b, states)) != OXHIP_OK) return st;
         bool any_running = false;
         for (auto& s : states) if (s.stop_reason == OXHIP_STOP_ITERATIONS) { any_running = true; break; }
         if (!any_running) break;
@@ -698,7 +703,7 @@ int32_t oxhip_rrt_batch_solve(oxhip_rrt_batch* b, uint64_t max_iterations, doubl
             break;
         }
     }
-    if ((st = read_states(b, states)) != OXHIP_OK) return st;
+    if (states.empty() && (st = read_states(b, states)) != OXHIP_OK) return st;   // (no launch: max_iterations = 0)
     for (auto& s : states)
         if (s.stop_reason == OXHIP_STOP_INTERNAL) return fail(OXHIP_ERR_HIP, "resident kernel: scanner/resolver hand-off stalled");
     if (timed_out) {

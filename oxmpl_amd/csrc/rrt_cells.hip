@@ -1594,8 +1594,10 @@ uint32_t cells_head_blocks(uint32_t dim, uint32_t cap) {
 
 template <int DIM>
 static void launch_cells_dim(const DevParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL((cells_prepare_kernel<DIM>), dim3(p.n_problems), dim3(64), 0, stream, p);
     const uint32_t split = p.freeze ? p.cells_split : 1u;
+    // the prepare pass builds missing grids and hands many-part launches their stream positions; a launch that needs neither skips it
+    if (!(p.cells_meta_ok != 0 && split <= kSelfSkipMax))
+        hipLaunchKernelGGL((cells_prepare_kernel<DIM>), dim3(p.n_problems), dim3(64), 0, stream, p);
     const uint32_t per_xcd = (p.n_problems + 7u) / 8u;
     const uint32_t wgs_per_xcd = (per_xcd * split + (uint32_t)kCellsWaves - 1u) / (uint32_t)kCellsWaves;
     dim3 grid(8u * wgs_per_xcd), block(kCellsWaves * 64);

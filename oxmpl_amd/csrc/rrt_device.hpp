@@ -146,6 +146,7 @@ struct DevParams {
     CellAcc* cell_acc;       // [P] zero between launches
     uint64_t* cell_part_pos; // [P][8] stream position at which each part of a split frozen launch starts
     uint32_t cell_blocks, cell_level_max, cells_split;
+    uint32_t cells_meta_ok;  // host: every problem's grid record was written by a launch since the last setup / set_tree (no prepare pass needed)
     // the spheres a motion's midpoint can meet, looked up instead of screened: bit j of sph_grid[cell] is set when sphere j's filter
     // ball (sph_filt) reaches the cell's box (sph_grid_G cells along every axis of the bounds, dimensions 2 / 3)
     const uint64_t* sph_grid;
