@@ -152,9 +152,13 @@ __device__ __forceinline__ uint32_t cell_place(const CellGrid& g, const double x
 
 // Append `entry` to cell `cell` for the lanes with `pred`: slot = the cell's counter, atomically (several lanes of a round may
 // share a cell); slots beyond the head block go to chained blocks, one lane at a time (rare: a cell holds ~1 .. 2^D nodes).
-__device__ __forceinline__ void cells_insert(CellBlock* blk, uint32_t& pool_next, uint32_t cell, uint64_t entry, bool pred, uint32_t lane) {
+// In two halves, so that a round's commit can put its reductions and its checksum between the atomic and the use of its result.
+__device__ __forceinline__ uint32_t cells_insert_begin(CellBlock* blk, uint32_t cell, bool pred) {
     uint32_t slot = 0;
     if (pred) slot = __hip_atomic_fetch_add(&blk[cell].count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return slot;
+}
+__device__ __forceinline__ void cells_insert_finish(CellBlock* blk, uint32_t& pool_next, uint32_t cell, uint64_t entry, bool pred, uint32_t slot, uint32_t lane) {
     if (pred && slot < kBlkEntries) blk[cell].e[slot] = entry;
     uint64_t over = __ballot(pred && slot >= kBlkEntries);
     while (over != 0) {
@@ -180,6 +184,10 @@ __device__ __forceinline__ void cells_insert(CellBlock* blk, uint32_t& pool_next
         }
         if (lane == 0) blk[b].e[sj % kBlkEntries] = ej;
     }
+}
+__device__ __forceinline__ void cells_insert(CellBlock* blk, uint32_t& pool_next, uint32_t cell, uint64_t entry, bool pred, uint32_t lane) {
+    const uint32_t slot = cells_insert_begin(blk, cell, pred);
+    cells_insert_finish(blk, pool_next, cell, entry, pred, slot, lane);
 }
 
 // (Re)build the grid of problem `prob` for its n nodes: one wave.  Chooses the level from n, the box from the bounds, the
@@ -1223,6 +1231,9 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
         if (cut > 0) {
             const uint64_t cutm = first_n_mask(cut);
             const bool mine = lane < cut;
+            uint32_t ins_cell = 0, ins_slot = 0;
+            uint64_t ins_entry = 0;
+            bool ins_link = false;
             if (ins) {
                 const uint32_t idx = n + (uint32_t)__popcll(okm & below_mask(lane));
                 if (mine && ok) {
@@ -1244,9 +1255,9 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                         if (mine && ok && idx < kFlatCap)
                             flat[idx] = link ? cfloat4{tf[0], tf[1], tf[2], 0.0f} : cfloat4{__builtin_inff(), __builtin_inff(), __builtin_inff(), 0.0f};
                     } else {
-                        if (STAMP) { const uint64_t nw = (uint64_t)clock64(); t_c[0] += nw - t_cm; t_cm = nw; }
-                        cells_insert(blk, grid.pool_next, cell, entry, link, lane);
-                        if (STAMP) { const uint64_t nw = (uint64_t)clock64(); t_c[1] += nw - t_cm; t_cm = nw; }
+                        // (the slot comes back from the L2 while the reductions and the checksum below run; the entry is stored after them)
+                        ins_cell = cell; ins_entry = entry; ins_link = link;
+                        ins_slot = cells_insert_begin(blk, cell, link);
                     }
                     const double e = -wave_min_f64(link ? -err : 0.0);
                     if (e > grid.delta_node) grid.delta_node = (double)f32_up(e * (1.0 + 1e-9));
@@ -1273,6 +1284,11 @@ __global__ __launch_bounds__(kCellsWaves * 64, FROZEN ? OXHIP_CELLS_WAVES_PER_EU
                                                : uni64(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pw >> 32), (int)cut) << 32) |
                                                        (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pw, (int)cut));
                 st.checksum = st.checksum * pc + sum;
+            }
+            if (ins && grid.level != 0) {
+                if (STAMP) { const uint64_t nw = (uint64_t)clock64(); t_c[0] += nw - t_cm; t_cm = nw; }
+                cells_insert_finish(blk, grid.pool_next, ins_cell, ins_entry, ins_link, ins_slot, lane);
+                if (STAMP) { const uint64_t nw = (uint64_t)clock64(); t_c[1] += nw - t_cm; t_cm = nw; }
             }
             st.iterations += cut;
             st.accepted += (uint64_t)__popcll(okm & cutm);

@@ -181,3 +181,39 @@ def test_rrt_star_pair_search_keeps_its_shape(star_wire_asm):
     wbody = star_wire_asm.split(wire[0] + ":")[1].split("s_endpgm")[0]
     for bad in ("scratch_", "flat_load", "ds_write", "ds_read"):   # entries in registers: no struct bounced through memory
         assert bad not in wbody, bad
+
+
+@pytest.fixture(scope="module")
+def cells_asm(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("asm") / "rrt_cells.s")
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                           "-S", "--cuda-device-only", "-o", out, os.path.join(CSRC, "rrt_cells.hip")],
+                          stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def test_cells_headline_kernel_keeps_its_shape(cells_asm):
+    """rrt_cells_kernel<3, false, FROZEN>: the frozen specialisation fits three waves per SIMD (<= 168 registers,
+    at most a handful of spilled values outside the rounds) and three workgroups' LDS per CU, the growing one two waves without
+    spilling; a block's entries go through the packed binary32 pipe; the sampler's window, the staged nodes and the tail list
+    are LDS; neither hot loop flushes a cache (the device-scope release fences left are the ones around a rebuild, before the
+    literal tie loop and at the end of a growing launch)"""
+    meta = _kernels(cells_asm)
+    frozen = [k for k in meta if "rrt_cells_kernelILi3ELb0ELb1E" in k]
+    grow = [k for k in meta if "rrt_cells_kernelILi3ELb0ELb0E" in k]
+    assert len(frozen) == 1 and len(grow) == 1
+    f, g = meta[frozen[0]], meta[grow[0]]
+    assert f["vgpr_count"] <= 168 and f["vgpr_spill_count"] <= 24 and f["max_flat_workgroup_size"] == 256, f
+    assert g["vgpr_count"] <= 256 and g["vgpr_spill_count"] == 0 and g["private_segment_fixed_size"] == 0, g
+    assert f["group_segment_fixed_size"] <= 160 * 1024 // 3 and g["group_segment_fixed_size"] <= 160 * 1024 // 2
+    fbody = cells_asm.split(frozen[0] + ":")[1].split("s_endpgm")[0]
+    gbody = cells_asm.split(grow[0] + ":")[1].split("s_endpgm")[0]
+    for body in (fbody, gbody):
+        assert body.count("v_pk_fma_f32") >= 100 and body.count("v_pk_mul_f32") >= 20
+        assert body.count("v_cvt_f32_u32_sdwa") >= 100          # 16-bit coordinates converted straight out of their words
+        assert "ds_bpermute_b32" in body                        # the tail pass fetches its pair's query across lanes
+    # L2 write-backs (buffer_wbl2): none in a frozen launch's code but the tie loop's, few in the growing kernel
+    assert fbody.count("buffer_wbl2") <= 1, fbody.count("buffer_wbl2")
+    assert gbody.count("buffer_wbl2") <= 6, gbody.count("buffer_wbl2")
+    # the resolver's exact work is unfused binary64
+    assert fbody.count("v_mul_f64") > 50 and fbody.count("v_add_f64") > 50

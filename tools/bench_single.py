@@ -60,10 +60,13 @@ def leg_a(seeds):
     return rows
 
 
+KERNEL = int(sys.argv[sys.argv.index("--kernel") + 1]) if "--kernel" in sys.argv else capi.KERNEL_AUTO   # (leg B / C only)
+
+
 def leg_b(P, nodes=10000):
     sc = scenarios.config2()
     t0 = time.perf_counter()
-    g = scenarios.make_batch(sc, P, nodes, False, 42, 0, 0, capi.KERNEL_AUTO)
+    g = scenarios.make_batch(sc, P, nodes, False, 42, 0, 0, KERNEL)
     t1 = time.perf_counter()
     g.solve(10 ** 7)
     t2 = time.perf_counter()
