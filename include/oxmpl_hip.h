@@ -104,9 +104,9 @@ typedef enum oxhip_debug_flag {
 } oxhip_debug_flag;
 
 typedef enum oxhip_kernel_kind {
-    OXHIP_KERNEL_AUTO = 0,      /* RRT (and the geometry of the decoupled RRT*): OXHIP_KERNEL_CELLS in R^2 / R^3 for batches of more than 256
-                                   problems (trees up to 64,512 nodes); OXHIP_KERNEL_LANES when the tree fits its register rows (R^4 .. R^6,
-                                   and small batches -- a CU per problem halves a single problem's latency); else streaming */
+    OXHIP_KERNEL_AUTO = 0,      /* RRT (and the geometry of the decoupled RRT*): OXHIP_KERNEL_CELLS in R^2 / R^3 (trees up to 64,512
+                                   nodes; any batch size); OXHIP_KERNEL_LANES in R^4 .. R^6 when the tree fits its register rows;
+                                   else streaming */
     OXHIP_KERNEL_STREAM = 1,    /* tree streamed from HBM/L2 SoA arrays every iteration: any dimension <= 8, any tree size */
     OXHIP_KERNEL_RESIDENT = 2,  /* tree held in the workgroup's vector registers as binary64, every node scanned in binary64
                                    (R^2 / R^3, <= 10,240 nodes): no binary32 anywhere -- the cross-check of the screened kernels */

@@ -30,12 +30,12 @@ struct oxhip_rrt_batch {
     DevBuf<double> tree, goal_c, goal_thr, goal_r, sph_c, sph_thr, sph_filt, box_lo, box_hi;
     std::vector<double> sph_centres, sph_radii;  // host copies (AoS) for the filter thresholds
     bool filt_dirty = true;
-    DevBuf<CellBlock> cell_blk;     // rrt_cells.hip: cell blocks, flat lists of small trees, grid descriptors, accumulators of split frozen launches
-    DevBuf<float> cell_flat;
-    DevBuf<double> cell_xyz;
-    DevBuf<CellMeta> cell_meta;
-    DevBuf<CellAcc> cell_acc;
-    DevBuf<uint64_t> cell_part_pos, sph_grid;
+    // rrt_cells.hip: cell blocks, flat lists of small trees, node-major coordinates, grid descriptors, accumulators and part
+    // positions of split frozen launches, the sphere mask grid -- ONE allocation (a hipMalloc costs more than a small kernel:
+    // the one-problem Planner::solve pays for every one of them), carved at 256-byte boundaries
+    DevBuf<uint8_t> cell_arena;
+    CellMeta* cell_meta_p = nullptr;
+    uint64_t* sph_grid_p = nullptr;
     ProblemState* h_states = nullptr;   // pinned: the state array as the host reads it after every launch
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
@@ -200,8 +200,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         chk(b->parent_b.alloc((size_t)P * cap));
     }
     if (cfg->planner == OXHIP_PLANNER_RRT_STAR) {
-        const bool geo_cells = cfg->kernel != OXHIP_KERNEL_LANES && cells_supported(dim, cap) &&
-                               !(cfg->kernel == OXHIP_KERNEL_AUTO && P <= 256u && lanes_supported(dim, cap));   // (small batches: see KERNEL_AUTO below)
+        const bool geo_cells = cfg->kernel != OXHIP_KERNEL_LANES && cells_supported(dim, cap);
         const bool geo_lanes = cfg->kernel != OXHIP_KERNEL_CELLS && lanes_supported(dim, cap);
         const bool can_wire = star_wire_supported(dim) && (geo_cells || geo_lanes);
         b->star_wired = cfg->kernel == OXHIP_KERNEL_LANES || cfg->kernel == OXHIP_KERNEL_CELLS || (cfg->kernel == OXHIP_KERNEL_AUTO && can_wire);
@@ -276,12 +275,11 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     if (cfg->planner != OXHIP_PLANNER_RRT) kind = b->star_wired ? (b->star_geo_cells ? OXHIP_KERNEL_CELLS : OXHIP_KERNEL_LANES) : OXHIP_KERNEL_STREAM;
     if (kind == OXHIP_KERNEL_AUTO)
     {
-        // rrt_cells.hip runs one WAVE per problem: a batch fills the chip from ~1,000 problems on (one wave per SIMD) and a growing
-        // tree takes ~12 ms to reach 10,000 nodes whatever the batch size; rrt_lanes.hip gives every problem a whole CU: 5.7 ms for
-        // the same tree, but only 256 problems at a time.  So small batches -- the one-problem Planner::solve of the trait surface
-        // above all -- run the latter (profiles/r3_single/), larger ones the former.
-        const bool small_batch = P <= 256u && lanes_supported(dim, cap);
-        kind = (cells_supported(dim, cap) && !small_batch) ? OXHIP_KERNEL_CELLS : lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
+        // rrt_cells.hip (one wave per problem, R^2 / R^3, trees up to 64,512 nodes) wherever it exists: since its rounds
+        // repair overtaken queries in place it grows ONE tree to 10,000 nodes in 4.3 ms -- faster than rrt_lanes.hip, which gives
+        // the problem a whole CU (5.6 ms) -- and 256 of them in 4.9 ms (6.2 ms), profiles/r3_single/.  rrt_lanes.hip serves
+        // R^4 .. R^6 (and trees that fit its register rows), rrt_stream.hip everything else.
+        kind = cells_supported(dim, cap) ? OXHIP_KERNEL_CELLS : lanes_supported(dim, cap) ? OXHIP_KERNEL_LANES : OXHIP_KERNEL_STREAM;
     }
     if (kind == OXHIP_KERNEL_CELLS) {
         if (!cells_supported(dim, cap)) {
@@ -296,23 +294,29 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         uint32_t split = cfg->frozen_split;
         if (split == 0) { split = (3072u + P - 1u) / P; if (split > 8u) split = 8u; if (split < 1u) split = 1u; }
         dp.cells_split = split;
-        hipError_t e2 = b->cell_blk.alloc((size_t)P * dp.cell_blocks);
-        if (e2 == hipSuccess) e2 = b->cell_flat.alloc((size_t)P * 4096 * 4);
-        if (e2 == hipSuccess) e2 = b->cell_xyz.alloc((size_t)P * cap * 4);
-        if (e2 == hipSuccess) e2 = b->cell_meta.alloc(P);
-        if (e2 == hipSuccess) e2 = b->cell_acc.alloc(P);
-        if (e2 == hipSuccess) e2 = b->cell_part_pos.alloc((size_t)P * 64);
         dp.sph_grid_G = sphere_grid_side(dim);
-        if (e2 == hipSuccess) e2 = b->sph_grid.alloc(dim == 2 ? (size_t)dp.sph_grid_G * dp.sph_grid_G : (size_t)dp.sph_grid_G * dp.sph_grid_G * dp.sph_grid_G);
-        if (e2 == hipSuccess) e2 = hipMemset(b->cell_meta.p, 0, (size_t)P * sizeof(CellMeta));
-        if (e2 == hipSuccess) e2 = hipMemset(b->cell_acc.p, 0, (size_t)P * sizeof(CellAcc));
+        const size_t grid_cells = dim == 2 ? (size_t)dp.sph_grid_G * dp.sph_grid_G : (size_t)dp.sph_grid_G * dp.sph_grid_G * dp.sph_grid_G;
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t at = off; off = (off + bytes + 255u) & ~(size_t)255u; return at; };
+        const size_t o_meta = carve((size_t)P * sizeof(CellMeta)), o_acc = carve((size_t)P * sizeof(CellAcc));   // (zeroed together)
+        const size_t zero_bytes = off;
+        const size_t o_pos = carve((size_t)P * 64 * sizeof(uint64_t)), o_grid = carve(grid_cells * sizeof(uint64_t));
+        const size_t o_flat = carve((size_t)P * 4096 * 4 * sizeof(float)), o_xyz = carve((size_t)P * cap * 4 * sizeof(double));
+        const size_t o_blk = carve((size_t)P * dp.cell_blocks * sizeof(CellBlock));
+        hipError_t e2 = b->cell_arena.alloc(off);
+        if (e2 == hipSuccess) e2 = hipMemset(b->cell_arena.p, 0, zero_bytes);
         if (e2 != hipSuccess) {
             std::string msg = std::string("device allocation failed: ") + hipGetErrorString(e2);
             oxhip_rrt_batch_destroy(b);
             return fail(OXHIP_ERR_HIP, msg);
         }
-        dp.cell_blk = b->cell_blk.p; dp.cell_flat = b->cell_flat.p; dp.cell_xyz = b->cell_xyz.p; dp.cell_meta = b->cell_meta.p;
-        dp.cell_acc = b->cell_acc.p; dp.cell_part_pos = b->cell_part_pos.p; dp.sph_grid = b->sph_grid.p;
+        uint8_t* base = b->cell_arena.p;
+        b->cell_meta_p = reinterpret_cast<CellMeta*>(base + o_meta);
+        b->sph_grid_p = reinterpret_cast<uint64_t*>(base + o_grid);
+        dp.cell_blk = reinterpret_cast<CellBlock*>(base + o_blk); dp.cell_flat = reinterpret_cast<float*>(base + o_flat);
+        dp.cell_xyz = reinterpret_cast<double*>(base + o_xyz); dp.cell_meta = b->cell_meta_p;
+        dp.cell_acc = reinterpret_cast<CellAcc*>(base + o_acc); dp.cell_part_pos = reinterpret_cast<uint64_t*>(base + o_pos);
+        dp.sph_grid = b->sph_grid_p;
     }
     if (kind == OXHIP_KERNEL_LANES && !lanes_supported(dim, cap)) {
         oxhip_rrt_batch_destroy(b);
@@ -451,7 +455,7 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
                              (size_t)P * dim, hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipMemsetAsync(b->skip.p, 0, (size_t)P * cap, b->stream));
     if (b->shadow_state.p) HIP_TRY(hipMemsetAsync(b->shadow_state.p, 0, (size_t)P * 2 * sizeof(uint32_t), b->stream));  // shadows start over
-    if (b->cell_meta.p) HIP_TRY(hipMemsetAsync(b->cell_meta.p, 0, (size_t)P * sizeof(CellMeta), b->stream));              // the grids too
+    if (b->cell_meta_p) HIP_TRY(hipMemsetAsync(b->cell_meta_p, 0, (size_t)P * sizeof(CellMeta), b->stream));              // the grids too
     b->dp.cells_meta_ok = 0;
     std::vector<int32_t> minus1(P, -1);
     HIP_TRY(hipMemcpy2DAsync(b->parent.p, (size_t)cap * sizeof(int32_t), minus1.data(), sizeof(int32_t),
@@ -500,7 +504,7 @@ static int32_t refresh_filter(oxhip_rrt_batch* b) {
     int32_t st = upload(b->sph_filt, f, b->stream);
     if (st != OXHIP_OK) return st;
     b->dp.sph_filt = b->sph_filt.p;
-    if (b->sph_grid.p && n > 0) launch_sphere_grid(b->dp, b->sph_grid.p, b->stream);   // (rrt_cells.hip looks the midpoint filter up)
+    if (b->sph_grid_p && n > 0) launch_sphere_grid(b->dp, b->sph_grid_p, b->stream);   // (rrt_cells.hip looks the midpoint filter up)
     if (b->star_wired) {   // motion_seq.hpp filters motions of any length: it takes the radii as given and this absolute margin
         if ((st = upload(b->sph_r, b->sph_radii, b->stream)) != OXHIP_OK) return st;
         b->dp.sph_r = b->sph_r.p;
@@ -558,7 +562,7 @@ int32_t oxhip_rrt_batch_set_tree(oxhip_rrt_batch* b, uint32_t problem, const dou
     HIP_TRY(hipMemcpyAsync(b->skip.p + (size_t)problem * cap, skip.data(), n, hipMemcpyHostToDevice, b->stream));
     if (b->shadow_state.p)   // this problem's fl32 shadow starts over
         HIP_TRY(hipMemsetAsync(b->shadow_state.p + 2 * (size_t)problem, 0, 2 * sizeof(uint32_t), b->stream));
-    if (b->cell_meta.p) HIP_TRY(hipMemsetAsync(b->cell_meta.p + problem, 0, sizeof(CellMeta), b->stream));   // ... and its cell grid
+    if (b->cell_meta_p) HIP_TRY(hipMemsetAsync(b->cell_meta_p + problem, 0, sizeof(CellMeta), b->stream));   // ... and its cell grid
     b->dp.cells_meta_ok = 0;
     std::vector<ProblemState> states;
     if ((st = read_states(b, states)) != OXHIP_OK) return st;

@@ -56,6 +56,9 @@ constexpr int kMaxShell = 6;                         // the cooperative search g
 #ifndef OXHIP_CELLS_NB_FROZEN
 #define OXHIP_CELLS_NB_FROZEN 3                      // ... of a frozen launch (three waves per SIMD hide the latency; 16 registers per cell in flight)
 #endif
+#ifndef OXHIP_CELLS_FILL_X2
+#define OXHIP_CELLS_FILL_X2 7ull
+#endif
 #ifndef OXHIP_CELLS_TAIL
 #define OXHIP_CELLS_TAIL 64                          // at most this many outstanding (query, cell) pairs: one pair per lane (0: off)
 #endif
@@ -98,7 +101,7 @@ __host__ __device__ __forceinline__ uint32_t cells_G(uint32_t level) {
     return t[level < 14u ? level : 14u];
 }
 __host__ __device__ __forceinline__ uint32_t cells_level_cap(uint32_t level, int dim) {   // largest tree level `level` serves
-    unsigned long long v = 7ull;
+    unsigned long long v = OXHIP_CELLS_FILL_X2;   // (twice the nodes per cell a level may reach)
     for (int k = 0; k < dim; ++k) v *= cells_G(level);
     v >>= 1;
     return v > 0xFFFFFFFEull ? 0xFFFFFFFEu : (uint32_t)v;

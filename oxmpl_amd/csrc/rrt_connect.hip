@@ -12,7 +12,10 @@
 
 namespace oxhip {
 
-constexpr int kConnThreads = 256;
+#ifndef OXHIP_CONN_THREADS
+#define OXHIP_CONN_THREADS 256
+#endif
+constexpr int kConnThreads = OXHIP_CONN_THREADS;
 constexpr int kConnWaves = kConnThreads / 64;
 
 constexpr int kConnLdsBytes = 36864;   // LDS for the two trees of one problem; 4 workgroups per CU fit in 160 KB
