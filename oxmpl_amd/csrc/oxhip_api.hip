@@ -36,6 +36,8 @@ struct oxhip_rrt_batch {
     DevBuf<uint8_t> cell_arena;
     CellMeta* cell_meta_p = nullptr;
     uint64_t* sph_grid_p = nullptr;
+    uint64_t* star_grid_p = nullptr;   // RRT*'s edge checks: the mask grid for motions up to search_radius long
+    DevBuf<double> star_filt;
     ProblemState* h_states = nullptr;   // pinned: the state array as the host reads it after every launch
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
@@ -301,6 +303,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         const size_t o_meta = carve((size_t)P * sizeof(CellMeta)), o_acc = carve((size_t)P * sizeof(CellAcc));   // (zeroed together)
         const size_t zero_bytes = off;
         const size_t o_pos = carve((size_t)P * 64 * sizeof(uint64_t)), o_grid = carve(grid_cells * sizeof(uint64_t));
+        const size_t o_grid2 = carve(b->star_wired ? grid_cells * sizeof(uint64_t) : 0);
         const size_t o_flat = carve((size_t)P * 4096 * 4 * sizeof(float)), o_xyz = carve((size_t)P * cap * 4 * sizeof(double));
         const size_t o_blk = carve((size_t)P * dp.cell_blocks * sizeof(CellBlock));
         hipError_t e2 = b->cell_arena.alloc(off);
@@ -313,6 +316,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
         uint8_t* base = b->cell_arena.p;
         b->cell_meta_p = reinterpret_cast<CellMeta*>(base + o_meta);
         b->sph_grid_p = reinterpret_cast<uint64_t*>(base + o_grid);
+        if (b->star_wired) b->star_grid_p = reinterpret_cast<uint64_t*>(base + o_grid2);
         dp.cell_blk = reinterpret_cast<CellBlock*>(base + o_blk); dp.cell_flat = reinterpret_cast<float*>(base + o_flat);
         dp.cell_xyz = reinterpret_cast<double*>(base + o_xyz); dp.cell_meta = b->cell_meta_p;
         dp.cell_acc = reinterpret_cast<CellAcc*>(base + o_acc); dp.cell_part_pos = reinterpret_cast<uint64_t*>(base + o_pos);
@@ -504,11 +508,27 @@ static int32_t refresh_filter(oxhip_rrt_batch* b) {
     int32_t st = upload(b->sph_filt, f, b->stream);
     if (st != OXHIP_OK) return st;
     b->dp.sph_filt = b->sph_filt.p;
-    if (b->sph_grid_p && n > 0) launch_sphere_grid(b->dp, b->sph_grid_p, b->stream);   // (rrt_cells.hip looks the midpoint filter up)
+    if (b->sph_grid_p && n > 0) launch_sphere_grid(b->dp, b->sph_grid_p, b->sph_filt.p, b->stream);   // (rrt_cells.hip looks the midpoint filter up)
     if (b->star_wired) {   // motion_seq.hpp filters motions of any length: it takes the radii as given and this absolute margin
         if ((st = upload(b->sph_r, b->sph_radii, b->stream)) != OXHIP_OK) return st;
         b->dp.sph_r = b->sph_r.p;
         b->dp.filt_abs = 1e-9 * maxabs;
+        b->dp.star_sph_grid = nullptr;
+        if (b->star_grid_p && n > 0) {
+            // the edge kernel's midpoint filter keeps sphere j when d2(centre, mid) <= (r_j + h)^2 (1 + 1e-9), h = dist / 2 (1 + 1e-6)
+            // + filt_abs, dist < search_radius: the grid is built for the largest such ball (either end of h's range when r_j < 0)
+            const double h_lo = b->dp.filt_abs, h_hi = 0.5 * b->cfg.search_radius * (1.0 + 1e-6) + b->dp.filt_abs;
+            std::vector<double> sf(n);
+            for (uint32_t j = 0; j < n; ++j) {
+                const double r = b->sph_radii[j];
+                const double a = (r + h_lo) * (r + h_lo), c = (r + h_hi) * (r + h_hi);
+                sf[j] = (std::isnan(r) || std::isinf(r)) ? std::numeric_limits<double>::infinity()
+                                                         : std::fmax(a, c) * (1.0 + 1e-9) * (1.0 + 1e-12);
+            }
+            if ((st = upload(b->star_filt, sf, b->stream)) != OXHIP_OK) return st;
+            launch_sphere_grid(b->dp, b->star_grid_p, b->star_filt.p, b->stream);
+            b->dp.star_sph_grid = b->star_grid_p;
+        }
     }
     b->filt_dirty = false;
     return OXHIP_OK;

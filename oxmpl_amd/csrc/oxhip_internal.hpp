@@ -61,7 +61,7 @@ uint32_t cells_level_max(uint32_t dim, uint32_t cap);
 uint32_t cells_head_blocks(uint32_t dim, uint32_t cap);
 void launch_rrt_cells(const DevParams& p, hipStream_t stream);
 uint32_t sphere_grid_side(uint32_t dim);                                  // cells along an axis of DevParams::sph_grid
-void launch_sphere_grid(const DevParams& p, uint64_t* grid, hipStream_t stream);   // (re)builds it from sph_c / sph_filt
+void launch_sphere_grid(const DevParams& p, uint64_t* grid, const double* filt, hipStream_t stream);   // (re)builds it from sph_c and the filter thresholds
 
 // prm_kernels.hip: PRM roadmap construction / query (prm.rs)
 struct PrmState {            // persists in HBM between launches

@@ -1567,9 +1567,9 @@ __global__ __launch_bounds__(64) void cells_prepare_kernel(DevParams p) {
     }
 }
 
-// DevParams::sph_grid: one thread per cell of the bounds' grid; bit j = sphere j's filter ball (every midpoint within sqrt(sph_filt)
-// of the centre) reaches the cell's box, taken 2^-9 of a cell wider on every side.  (NaN / +inf thresholds: always set.)
-__global__ __launch_bounds__(256) void sphere_grid_kernel(DevParams p, uint64_t* grid) {
+// DevParams::sph_grid / star_sph_grid: one thread per cell of the bounds' grid; bit j = sphere j's filter ball (every midpoint within
+// sqrt(filt[j]) of the centre) reaches the cell's box, taken 2^-9 of a cell wider on every side.  (NaN / +inf thresholds: always set.)
+__global__ __launch_bounds__(256) void sphere_grid_kernel(DevParams p, uint64_t* grid, const double* filt) {
     const uint32_t G = p.sph_grid_G, dim = p.dim;
     const uint32_t cells = dim == 2 ? G * G : G * G * G;
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
@@ -1586,14 +1586,14 @@ __global__ __launch_bounds__(256) void sphere_grid_kernel(DevParams p, uint64_t*
             const double e = fmax(fmax(blo - c, c - bhi), 0.0);
             d2 += e * e;
         }
-        if (!(d2 * (1.0 - 1e-9) > p.sph_filt[j])) mask |= 1ull << j;
+        if (!(d2 * (1.0 - 1e-9) > filt[j])) mask |= 1ull << j;
     }
     grid[idx] = mask;
 }
 uint32_t sphere_grid_side(uint32_t dim) { return dim == 2 ? 128u : 32u; }
-void launch_sphere_grid(const DevParams& p, uint64_t* grid, hipStream_t stream) {
+void launch_sphere_grid(const DevParams& p, uint64_t* grid, const double* filt, hipStream_t stream) {
     const uint32_t G = p.sph_grid_G, cells = p.dim == 2 ? G * G : G * G * G;
-    hipLaunchKernelGGL(sphere_grid_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, stream, p, grid);
+    hipLaunchKernelGGL(sphere_grid_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, stream, p, grid, filt);
 }
 
 bool cells_supported(uint32_t dim, uint32_t cap) { return (dim == 2 || dim == 3) && cap <= 65535u; }   // (a block entry names its node with 16 bits)

@@ -151,6 +151,7 @@ struct DevParams {
     // ball (sph_filt) reaches the cell's box (sph_grid_G cells along every axis of the bounds, dimensions 2 / 3)
     const uint64_t* sph_grid;
     uint32_t sph_grid_G;
+    const uint64_t* star_sph_grid;   // the same for RRT*'s edge checks: filter balls of motions up to search_radius long (null: none)
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -287,13 +287,35 @@ __global__ __launch_bounds__(256) void star_edges_kernel(DevParams p) {
                 continue;
             }
             uint64_t mask = 0;
-            for (uint32_t jj = 0; jj < cnt; ++jj) {
-                double c[DIM];
+            bool looked_up = false;
+            if (DIM <= 3 && w0 == 0 && p.star_sph_grid != nullptr) {
+                // the first 64 spheres in R^2 / R^3: the midpoint's cell of the mask grid (rrt_cells.hip, sphere_grid_kernel; built
+                // for the longest motion a neighbour pair can have) names a superset of what the loop below would keep
+                const uint32_t G = p.sph_grid_G;
+                bool inside = true;
+                uint32_t ci[3] = {0u, 0u, 0u};
 #pragma unroll
-                for (int k = 0; k < DIM; ++k) c[k] = sc[k][jj];
-                const double rr = srad[jj] + h;
-                const double lim = rr * rr * (1.0 + 1e-9);
-                if (!(dist2<DIM>(c, mid, DIM) > lim)) mask |= 1ull << jj;   // NaN / inf radii stay in
+                for (int k = 0; k < DIM; ++k) {
+                    const double u = (mid[k] - p.lo[k]) * ((double)G / (p.hi[k] - p.lo[k]));
+                    inside = inside && u >= -0x1p-10 && u <= (double)G + 0x1p-10;   // (NaN: outside)
+                    const double fl = floor(u);
+                    ci[k] = fl > 0.0 ? (fl < (double)G ? (uint32_t)fl : G - 1u) : 0u;
+                }
+                if (inside) {
+                    mask = p.star_sph_grid[DIM == 3 ? (ci[2] * G + ci[1]) * G + ci[0] : ci[1] * G + ci[0]];
+                    if (cnt < 64u) mask &= (1ull << cnt) - 1ull;
+                    looked_up = true;
+                }
+            }
+            if (!looked_up) {
+                for (uint32_t jj = 0; jj < cnt; ++jj) {
+                    double c[DIM];
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) c[k] = sc[k][jj];
+                    const double rr = srad[jj] + h;
+                    const double lim = rr * rr * (1.0 + 1e-9);
+                    if (!(dist2<DIM>(c, mid, DIM) > lim)) mask |= 1ull << jj;   // NaN / inf radii stay in
+                }
             }
             if (mask == 0) continue;
             // second, tighter filter for the few spheres the midpoint test left: every interpolated state of either motion is a
