@@ -2,7 +2,7 @@
 """Measurement of the RRT* row: BASELINE.json configs[1] scene (R^3, 64 spheres), 1024 independent
 problems grown from 1 to max_nodes nodes with RRTStar(0.5, 0.05, search_radius) on one MI355X, next to the CPU
 oracle on a bounded sample of the same problems.  Usage: bench_rrt_star.py [problems] [max_nodes] [search_radius] [kernel]
-(kernel 0 = KERNEL_AUTO: the decoupled design -- geometry by rrt_lanes.hip, wiring by rrt_star_wire.hip; 1 = rrt_star.hip)"""
+(kernel 0 = KERNEL_AUTO: the decoupled design -- geometry by rrt_cells.hip (R^2 / R^3) or rrt_lanes.hip, wiring by rrt_star_wire.hip; 1 = rrt_star.hip)"""
 import concurrent.futures as cf
 import json
 import os
@@ -68,7 +68,7 @@ acc = P * (N - 1)
 alg_bytes = 2 * 24 * P * (N - 1) * N / 2 + (its - acc) * 24 * N / 2
 print(json.dumps({"roofline": {"bound": "hbm", "achieved": alg_bytes / (k * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                "frac": alg_bytes / (k * 1e-3) / 1e9 / 8000.0, "algorithmic_bytes": alg_bytes},
-                  "planner": "RRTStar", "design": "decoupled: rrt_lanes.hip + rrt_star_wire.hip" if g.last_timing()["kernel"] == capi.KERNEL_LANES else "one kernel: rrt_star.hip",
+                  "planner": "RRTStar", "design": {capi.KERNEL_LANES: "decoupled: rrt_lanes.hip + rrt_star_wire.hip", capi.KERNEL_CELLS: "decoupled: rrt_cells.hip + rrt_star_wire.hip"}.get(g.last_timing()["kernel"], "one kernel: rrt_star.hip"),
                   "workload": "R^3, 64 spheres, %d problems, 1 -> %d nodes, search radius %g" % (P, N, R),
                   "kernel_ms": k, "iterations": its, "iterations_per_s": its / (k * 1e-3),
                   "nodes_per_s": P * (N - 1) / (k * 1e-3), "mean_goal_cost_sample": goal_cost,
