@@ -41,6 +41,7 @@ struct oxhip_rrt_batch {
     ProblemState* h_states = nullptr;   // pinned: the state array as the host reads it after every launch
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
+    DevBuf<uint16_t> seg_grid;      // ... and the cells' segment lists (rrt_connect_se2.hip, seg_grid_kernel)
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
     // RRT*: W of the checksum; the decoupled design's buffers (rrt_star_wire.hip)
     DevBuf<uint64_t> wire_chk;
@@ -180,6 +181,14 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.space = cfg->space;
     dp.max_distance = cfg->max_distance;
     dp.res = res;
+    if (cfg->space == OXHIP_SPACE_SE2) {   // rrt_connect_se2.hip: the step count of an Advanced extend's motion, when it is safely known
+        const double r = cfg->max_distance / res, c = std::ceil(r);
+        const double gap = std::fmin(r - (c - 1.0), c - r);
+        if (std::isfinite(r) && c >= 1.0 && c < 4294967295.0 && gap > 1e-6) {
+            dp.se2_adv_steps = (uint32_t)c;
+            dp.se2_adv_slack = 0.5 * gap * res;
+        }
+    }
     dp.p_int = bernoulli_p_int(cfg->goal_bias);
     dp.seed = cfg->seed;
     dp.dbg_flags = cfg->debug_flags;   // oxhip_debug_flag bits: test-only, results identical (the library reads no environment variable)
@@ -418,6 +427,18 @@ int32_t oxhip_rrt_batch_set_segments(oxhip_rrt_batch* b, const double* segments,
     b->dp.segs = b->segs.p;
     b->dp.n_segs = n;
     b->dp.seg_thr = sqrt_le_threshold(clearance);
+    // the grid the motion check looks its segments up in: over the (x, y) bounds, which are finite here (create() refused others)
+    b->dp.seg_grid = nullptr;
+    const double wx = b->dp.hi[0] - b->dp.lo[0], wy = b->dp.hi[1] - b->dp.lo[1];
+    if (n > 0 && (b->cfg.debug_flags & OXHIP_DEBUG_SE2_NO_SEGMENT_GRID) == 0 && std::isfinite(wx) && std::isfinite(wy) && wx > 0.0 && wy > 0.0) {
+        const uint32_t G = seg_grid_side();
+        if (b->seg_grid.n != (size_t)G * G * 8) HIP_TRY(b->seg_grid.alloc((size_t)G * G * 8));
+        b->dp.seg_grid_G = G;
+        b->dp.seg_grid_inv[0] = (double)G / wx;
+        b->dp.seg_grid_inv[1] = (double)G / wy;
+        launch_seg_grid(b->dp, b->seg_grid.p, clearance, b->stream);
+        b->dp.seg_grid = b->seg_grid.p;
+    }
     return OXHIP_OK;
 }
 

@@ -27,8 +27,10 @@ void launch_rng_u64(uint64_t seed, uint64_t stream, uint32_t n, uint64_t* out, h
 // rrt_connect.hip: RRTConnect (rrt_connect.rs), one 256-thread workgroup per problem, trees streamed from HBM/L2
 void launch_rrt_connect(const DevParams& p, hipStream_t stream);
 
-// rrt_connect_se2.hip: RRTConnect over SE(2) among line segments (BASELINE.json configs[3])
+// rrt_connect_se2.hip: RRTConnect over SE(2) among line segments (BASELINE.json configs[3]), one wave per problem
 void launch_rrt_connect_se2(const DevParams& p, hipStream_t stream);
+uint32_t seg_grid_side();                                                 // cells along an axis of DevParams::seg_grid
+void launch_seg_grid(const DevParams& p, uint16_t* grid, double clearance, hipStream_t stream);   // (re)builds it from segs
 void launch_se2_op(uint32_t op, const double* a, const double* b, const double* t, uint32_t n, double* out, hipStream_t s);
 void launch_se2_is_valid(const DevParams& p, const double* states, uint32_t n, uint8_t* out, hipStream_t s);
 void launch_se2_check_motion(const DevParams& p, const double* from, const double* to, uint32_t n, uint8_t* out, hipStream_t s);

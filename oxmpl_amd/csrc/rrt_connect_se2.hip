@@ -10,14 +10,15 @@
 // node's distance is evaluated exactly as the reference would (sqrt + fmod per node) and the argmin is the
 // lexicographic (distance, index) minimum.  Validity: a disc of radius `clearance` among line segments, decided
 // as d2(point, segment) > T(clearance) with the host-computed exact threshold (no sqrt, no transcendental).
-// One 256-thread workgroup per problem, both trees as SoA [3][cap] arrays in HBM / L2.
+// ONE WAVE PER PROBLEM (a 64-thread workgroup, four per CU): an iteration is a chain of dependent steps -- sample, scan, steer,
+// motion check, insert, twice -- so what counts is the length of that chain, not throughput.  Both trees are mirrored in LDS
+// (the SoA [3][cap] arrays in HBM receive every store), nothing waits at a barrier, and the motion check looks its segments up
+// in a grid instead of sweeping the soup (seg_grid_kernel below).
 #include "oxhip_internal.hpp"
 #include "rrt_device.hpp"
 
 namespace oxhip {
 
-constexpr int kSe2Threads = 256;
-constexpr int kSe2Waves = kSe2Threads / 64;
 #define OXHIP_PI 3.14159265358979323846   // std::f64::consts::PI = 0x400921FB54442D18
 
 // f64::rem_euclid(a, 2*PI): r = a % (2*PI); if r < 0.0 { r + 2*PI } else { r }.  fmod is exact, and for
@@ -58,9 +59,9 @@ __device__ __forceinline__ void se2_interpolate(const double from[3], const doub
 
 // squared distance from (px, py) to segment j: project onto the segment (t clamped to [0,1], a degenerate
 // segment or NaN gives t = 0), every operation rounded separately in exactly this order (it defines the checker)
-__device__ __forceinline__ double point_segment_d2(const DevParams& p, double px, double py, uint32_t j) {
-    const double ax = p.segs[4 * (size_t)j], ay = p.segs[4 * (size_t)j + 1];
-    const double bx = p.segs[4 * (size_t)j + 2], by = p.segs[4 * (size_t)j + 3];
+__device__ __forceinline__ double point_segment_d2(const double* segs, double px, double py, uint32_t j) {
+    const double ax = segs[4 * (size_t)j], ay = segs[4 * (size_t)j + 1];
+    const double bx = segs[4 * (size_t)j + 2], by = segs[4 * (size_t)j + 3];
     const double abx = bx - ax, aby = by - ay;
     const double apx = px - ax, apy = py - ay;
     const double l1 = abx * abx, l2 = aby * aby;
@@ -81,90 +82,380 @@ __device__ __forceinline__ double point_segment_d2(const DevParams& p, double px
 }
 // is the state invalid because of segment j?  valid iff sqrt(d2) > clearance  <=>  d2 > seg_thr
 __device__ __forceinline__ bool segment_hit(const DevParams& p, const double s[3], uint32_t j) {
-    return !(point_segment_d2(p, s[0], s[1], j) > p.seg_thr);
+    return !(point_segment_d2(p.segs, s[0], s[1], j) > p.seg_thr);
 }
 
-// rrt_connect.rs:166-189 for `nthreads` callers (a multiple of 64); returns this caller's flag.  The steps are
-// dealt to the waves and the segments to the lanes: the interpolated state (one normalisation chain) is computed
-// once per step and is wave-uniform, no index division is needed.
-__device__ __forceinline__ bool se2_motion_invalid_partial(const DevParams& p, const double from[3], const double to[3],
-                                                           uint32_t tid, uint32_t nthreads) {
+// ---- the checker's segments, looked up instead of swept (DevParams::seg_grid)
+//
+// A motion check tests 7 states against 256 segments in configs[3], and all but a handful of those 1,792 tests are against segments
+// far away.  seg_grid_kernel (run when the segments change) files the soup in a kSegGridG x kSegGridG grid over the (x, y) bounds:
+// a cell lists the (up to kSegSlots) segments that can come within `clearance` of ANY point of the cell, ascending, 0xFFFF = no more;
+// a cell that more segments reach says kSegOverflow in its first slot, and its states -- like states outside the bounds -- are
+// tested against every segment.  "Can come within": d(centre, segment) <= clearance + h, h = the cell's half diagonal taken 2^-8
+// wider (the triangle inequality; the widening and the relative 1e-9 are orders of magnitude above the roundings of
+// point_segment_d2 and of the cell index).  A segment a cell does not list is farther than the clearance from every state in the
+// cell, its test would come out "no hit", and is_valid is the conjunction of those tests: same verdicts, by construction.
+constexpr uint32_t kSegGridG = 128;
+constexpr int kSegSlots = 8;
+constexpr uint32_t kSegNone = 0xFFFFu, kSegOverflow = 0xFFFEu;
+
+__global__ __launch_bounds__(256) void seg_grid_kernel(DevParams p, uint16_t* grid, double clearance) {
+    const uint32_t G = p.seg_grid_G, idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= G * G) return;
+    const uint32_t ix = idx % G, iy = idx / G;
+    const double wx = (p.hi[0] - p.lo[0]) / (double)G, wy = (p.hi[1] - p.lo[1]) / (double)G;
+    const double cx = p.lo[0] + ((double)ix + 0.5) * wx, cy = p.lo[1] + ((double)iy + 0.5) * wy;
+    const double h = 0.5 * sqrt(wx * wx + wy * wy) * (1.0 + 0x1p-8);
+    const double R = (clearance > 0.0 ? clearance : 0.0) + h, R2 = R * R * (1.0 + 1e-9);
+    uint32_t cnt = 0;
+    uint16_t ids[kSegSlots];
+#pragma unroll
+    for (int k = 0; k < kSegSlots; ++k) ids[k] = (uint16_t)kSegNone;
+    const uint32_t ns = p.n_segs < kSegOverflow ? p.n_segs : kSegOverflow;   // (ids beyond 16 bits: the cell overflows below)
+    for (uint32_t j = 0; j < ns; ++j) {
+        if (point_segment_d2(p.segs, cx, cy, j) > R2) continue;   // (NaN: listed)
+        if (cnt < (uint32_t)kSegSlots) {
+#pragma unroll
+            for (int k = 0; k < kSegSlots; ++k) if ((uint32_t)k == cnt) ids[k] = (uint16_t)j;
+        }
+        ++cnt;
+    }
+    if (cnt > (uint32_t)kSegSlots || p.n_segs > ns) ids[0] = (uint16_t)kSegOverflow;
+    uint4 e;
+    e.x = ids[0] | ((uint32_t)ids[1] << 16); e.y = ids[2] | ((uint32_t)ids[3] << 16);
+    e.z = ids[4] | ((uint32_t)ids[5] << 16); e.w = ids[6] | ((uint32_t)ids[7] << 16);
+    reinterpret_cast<uint4*>(grid)[idx] = e;
+}
+uint32_t seg_grid_side() { return kSegGridG; }
+void launch_seg_grid(const DevParams& p, uint16_t* grid, double clearance, hipStream_t stream) {
+    const uint32_t cells = p.seg_grid_G * p.seg_grid_G;
+    hipLaunchKernelGGL(seg_grid_kernel, dim3((cells + 255u) / 256u), dim3(256), 0, stream, p, grid, clearance);
+}
+
+// rrt_connect.rs:166-189 for ONE WAVE; returns the wave-uniform verdict "some tested state is invalid".  Only (x, y) enter the
+// checker, so only they are interpolated (is_valid is pure: the heading's interpolation has no effect the reference could observe).
+// Up to eight states: eight lanes per state, lane k of a state takes slot k of its cell's list -- the whole check is one
+// point_segment_d2 deep.  More states: a lane per state, which walks its cell's list.
+// tdiv (optional, LDS): tdiv[n - 1][s] = (s + 1) / n for n, s + 1 <= 8 -- the quotients themselves, computed once per launch.
+__device__ __forceinline__ bool se2_motion_invalid_wave(const DevParams& p, const double* segs, const double from[3], const double to[3],
+                                                        uint32_t nsteps, uint32_t lane, const double (*tdiv)[8] = nullptr) {
     if (p.n_segs == 0) return false;
-    const double dist = se2_distance(from, to);
-    const uint32_t nsteps = num_steps_u32(dist, p.res);
-    const uint32_t wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
-    bool bad = false;
-    if (nsteps <= 1) {
-        for (uint32_t j = tid; j < p.n_segs; j += nthreads) bad = bad || segment_hit(p, to, j);
-        return bad;
-    }
+    const uint32_t S = nsteps <= 1 ? 1u : nsteps;               // states tested: `to` alone, or steps 1 ..= nsteps
+    const uint32_t g = S <= 8u ? 8u : 1u, per_pass = 64u / g;
+    const uint32_t k0 = lane & (g - 1u), sub = lane / g;
     const double dn = (double)nsteps;
-    for (uint32_t step = wave + 1; step <= nsteps && step > wave; step += nwaves) {   // `step > wave`: no wrap at 2^32
-        double s[3];
-        se2_interpolate(from, to, (double)step / dn, s);
-        for (uint32_t j = lane; j < p.n_segs; j += 64) bad = bad || segment_hit(p, s, j);
+    const uint4* grid = reinterpret_cast<const uint4*>(p.seg_grid);
+    for (uint32_t s0 = 0; s0 < S && s0 + per_pass > s0; s0 += per_pass) {
+        const uint32_t s = s0 + sub;
+        bool bad = false;
+        if (s < S) {
+            double x = to[0], y = to[1];
+            if (nsteps > 1) {
+                const double t = (tdiv && nsteps <= 8u) ? tdiv[nsteps - 1u][s] : (double)(s + 1u) / dn;
+                double xy[2];
+                lerp<2>(from, to, t, xy, 2);
+                x = xy[0]; y = xy[1];
+            }
+            uint4 e = make_uint4(0u, 0u, 0u, 0u);
+            bool all = true;
+            if (grid) {
+                const double fx = (x - p.lo[0]) * p.seg_grid_inv[0], fy = (y - p.lo[1]) * p.seg_grid_inv[1];
+                const double G = (double)p.seg_grid_G;
+                if (fx >= 0.0 && fx < G && fy >= 0.0 && fy < G) {   // (NaN: every segment)
+                    e = grid[(uint32_t)fy * p.seg_grid_G + (uint32_t)fx];
+                    all = (e.x & 0xFFFFu) == kSegOverflow;
+                }
+            }
+            if (all) {
+                for (uint32_t j = k0; j < p.n_segs; j += g) bad = bad || !(point_segment_d2(segs, x, y, j) > p.seg_thr);
+            } else {
+                const uint32_t w[4] = {e.x, e.y, e.z, e.w};
+                for (uint32_t k = k0; k < (uint32_t)kSegSlots; k += g) {
+                    uint32_t pair = w[0];
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) if ((k >> 1) == (uint32_t)q) pair = w[q];
+                    const uint32_t id = (k & 1u) ? pair >> 16 : pair & 0xFFFFu;
+                    if (id == kSegNone) break;
+                    bad = bad || !(point_segment_d2(segs, x, y, id) > p.seg_thr);
+                }
+            }
+        }
+        if (__ballot(bad) != 0) return true;
     }
-    return bad;
+    return false;
 }
 
-constexpr int kSe2LdsSegs = 512;   // segments staged in LDS (16 KB); larger soups are read from HBM / L2
+constexpr int kSe2N = 768;          // nodes of each tree shadowed in LDS (binary32); beyond that every node is evaluated exactly
+constexpr int kSe2LdsSegs = 256;    // segments staged in LDS; larger soups are read from HBM / L2
 
+// LDS of one problem = one wave = one workgroup: 36 KB, four problems per CU (one per SIMD)
 struct Se2Shared {
     uint32_t rng_buf[16][64];
-    Exact wave_exact[kSe2Waves];
+    float4 shadow_a[kSe2N];         // fl32(x, y, theta) of the start tree's nodes
+    float4 shadow_b[kSe2N];         // ... of the goal tree's
     double segs[kSe2LdsSegs][4];
+    double q[3][64];                // the samples of the current block of 64 iterations ...
+    uint64_t pos_after[64];         // ... and the stream position after each of them
+    double tdiv[8][8];              // (s + 1) / n, n = 1 .. 8 (se2_motion_invalid_wave)
+};
+static_assert(sizeof(Se2Shared) <= 40960, "four problems per CU");
+
+// Lane-parallel sampling of m <= 64 consecutive iterations (rrt_connect.rs:258-262 + the SE(2) sample_uniform; the scheme of
+// rrt_cells.hip's cells_sample): lane j draws iteration j.  Where its words start depends on how many of the iterations before
+// it sampled the goal (one word instead of four), so the goal mask is iterated to its fixed point: in round r the first r lanes
+// are right.  Returns false, nothing written, when a range draw was rejected or the window is too short.
+__device__ __forceinline__ bool se2_sample64(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane, Se2Shared& sh) {
+    const uint64_t win_lo = rng.base_blk * 8;
+    const uint64_t pos0 = rng.pos;
+    if (pos0 < win_lo || pos0 + (uint64_t)m * 4u > win_lo + 512) return false;
+    const uint32_t rel0 = (uint32_t)(pos0 - win_lo);
+    const bool act = lane < m;
+    const bool always_goal = p.p_int == ~0ull;   // Bernoulli ALWAYS_TRUE: no draw at all
+    auto word = [&](uint32_t rel) -> uint64_t {
+        const uint32_t a = rel0 + rel, bl = a >> 3, w = (a & 7u) * 2u;
+        return ((uint64_t)rng.buf[w + 1][bl] << 32) | rng.buf[w][bl];
+    };
+    uint64_t goal_mask = always_goal ? ~0ull : 0ull;
+    uint32_t off = 0u;
+    if (!always_goal) {
+        const uint64_t below = (1ull << lane) - 1ull;
+        for (uint32_t round = 0; round <= m; ++round) {
+            off = act ? 4u * lane - 3u * (uint32_t)__popcll(goal_mask & below) : 0u;
+            const uint64_t now = __ballot(act && word(off) < p.p_int);
+            if (now == goal_mask) break;
+            goal_mask = now;
+        }
+    }
+    const bool goal = (goal_mask >> lane) & 1ull;
+    double q[3];
+    bool redraw = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint64_t bits = (word(act && !goal ? off + 1u + (uint32_t)k : 0u) >> 12) | 0x3FF0000000000000ull;
+        const double v01 = __longlong_as_double((long long)bits) - 1.0;
+        double res = v01 * p.scale[k];
+        res = res + p.lo[k];
+        redraw = redraw || !(res < p.hi[k]);
+        q[k] = goal ? goal_c[k] : res;
+    }
+    if (__ballot(act && redraw && !goal) != 0) return false;
+    const uint32_t cnt = always_goal ? 0u : (goal ? 1u : 4u);
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sh.q[k][lane] = q[k];
+        sh.pos_after[lane] = pos0 + off + cnt;
+    }
+    rng.pos = pos0 + (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), (int)(m - 1));
+    return true;
+}
+__device__ __forceinline__ void se2_sample_block(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane, Se2Shared& sh) {
+    const uint64_t need_hi = rng.pos + (uint64_t)m * 4u;
+    if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
+        rng.base_blk = uni64(rng.pos >> 3);
+        uint32_t o[16];
+        chacha12_block(rng.seed, rng.base_blk + lane, rng.stream, o);
+#pragma unroll
+        for (int w = 0; w < 16; ++w) rng.buf[w][lane] = o[w];
+    }
+    if (!se2_sample64(rng, p, goal_c, m, lane, sh)) {
+        for (uint32_t b = 0; b < m; ++b) {   // (never expected) a redraw: one by one
+            double qn[3];
+            sample_state<3, false>(rng, p, 3, goal_c, qn);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) sh.q[k][b] = qn[k];
+                sh.pos_after[b] = rng.pos;
+            }
+        }
+    }
+}
+
+// One tree: the binary64 SoA arrays in HBM (every store lands there; the scan reads only its candidates back) and the binary32
+// shadow in LDS the scan screens with.
+struct Se2Tree {
+    double* g;        // SoA [3][cap] in HBM
+    float4* sh;       // LDS [kSe2N]
+    size_t cap;
+    __device__ __forceinline__ void load(uint32_t i, double c[3]) const { c[0] = g[i]; c[1] = g[cap + i]; c[2] = g[2 * cap + i]; }
 };
 
-// extend() of rrt_connect.rs:121-159; 0 = motion invalid, 1 = Advanced, 2 = Reached
-__device__ __forceinline__ int se2_extend(const DevParams& p, Se2Shared& sh, double* tree, int32_t* parent, size_t cap,
-                                          uint32_t& n, const double q[3], uint32_t& nearest, double q_new[3]) {
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+// what the screen's error bound depends on, wave-uniform, kept current by every insert
+struct Se2Range {
+    float mag;        // largest |x|, |y| of any node of either tree
+    bool theta_ok;    // every heading lies in [-PI, PI] (then the heading distance is min(|d|, 2 PI - |d|))
+};
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+constexpr float kSe2PiUp = 3.14159274f;   // fl32(PI), which is > PI
+__device__ __forceinline__ float se2_screen(const float4 s, float qx, float qy, float qt) {
+    const float dx = s.x - qx, dy = s.y - qy;
+    const float r = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+    const float a = fabsf(s.z - qt);
+    return r + 0.5f * fminf(a, 6.28318548f - a);
+}
+
+// Nearest node of rrt_connect.rs:128-136 under the compound distance: the lexicographic (distance, index) minimum over the tree, the
+// distance evaluated exactly as the reference does (sqrt + rem_euclid per node).  Evaluating that for every node is what an
+// iteration's time went into; here every node gets a binary32 estimate d^ first (|d^ - d| <= E, derivation in DESIGN.md section 11:
+// E = 32 * 2^-24 * (mag + PI) covers the roundings of the stored coordinates, of the differences, the 1-ulp square root, the fl32
+// 2 PI and the final sum about twice over), and only nodes with d^ <= min d^ + 2 E -- the true winner is always one of them -- are
+// evaluated exactly and compared.  Almost always that is one node.
+__device__ __forceinline__ void se2_nearest(const Se2Tree& tree, uint32_t n, const double q[3], const Se2Range& rg, uint32_t lane,
+                                            uint32_t& nearest, double& min_dist, double q_near[3]) {
+    const float qx = (float)q[0], qy = (float)q[1], qt = (float)q[2];
+    const uint32_t ns = n < (uint32_t)kSe2N ? n : (uint32_t)kSe2N;
+    const bool screen = rg.theta_ok && fabsf(qt) <= kSe2PiUp;
+    float thr = __builtin_inff();
+    bool slow = !screen || n > ns;
+    float b1 = __builtin_inff(), b2 = __builtin_inff();
+    uint32_t i1 = 0xFFFFFFFFu;
+    // (the loads below read what this wave stored earlier: drain its stores first -- they were issued an extend ago, no wait in practice)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     Exact e{__builtin_inf(), 0xFFFFFFFFu};
-    for (uint32_t i = tid; i < n; i += kSe2Threads) {   // indices ascend within a thread: strict < keeps the lowest
-        const double c[3] = {tree[i], tree[cap + i], tree[2 * cap + i]};
+    double c[3] = {0.0, 0.0, 0.0};
+    if (screen) {
+        const uint32_t trips = (ns + 63u) >> 6;   // uniform: four independent LDS reads per turn
+        for (uint32_t t = 0; t < trips; t += 4u) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t i = lane + ((t + (uint32_t)u) << 6); v[u] = tree.sh[i < ns ? i : 0u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = lane + ((t + (uint32_t)u) << 6);
+                const float d = i < ns ? se2_screen(v[u], qx, qy, qt) : __builtin_inff();
+                if (d < b1) { b2 = b1; b1 = d; i1 = i; }
+                else if (d < b2) b2 = d;
+            }
+        }
+        if (!slow && i1 != 0xFFFFFFFFu) tree.load(i1, c);   // in flight across the reduction: almost always it is the lane's only candidate
+        const float m = __uint_as_float(wave_min_u32(__float_as_uint(b1)));   // (estimates are >= +0: their bit patterns order like they do)
+        const float mag = fmaxf(rg.mag, fmaxf(fabsf(qx), fabsf(qy)));
+        thr = m + (mag + 3.2f) * (2.02f * 32.0f * 0x1p-24f);
+        slow = slow || __ballot(b2 <= thr) != 0;
+    }
+    if (!slow) {   // every lane holds at most one candidate: its best
+        const bool cand = b1 <= thr;
+        if (cand) {
+            e.dist = se2_distance(c, q);
+            e.idx = i1;
+        }
+        const uint64_t cm = __ballot(cand);
+        if ((cm & (cm - 1ull)) != 0) {   // several lanes: the reference's comparison among them
+            const Exact w = exact_wave_reduce(e);
+            const uint64_t wm = __ballot(cand && e.idx == w.idx);
+            const int L = __builtin_ctzll(wm);
+            nearest = w.idx;
+            min_dist = w.dist;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q_near[k] = readlane_f64(c[k], L);
+            return;
+        }
+        const int L = __builtin_ctzll(cm);
+        nearest = (uint32_t)__builtin_amdgcn_readlane((int)e.idx, L);
+        min_dist = readlane_f64(e.dist, L);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q_near[k] = readlane_f64(c[k], L);
+        return;
+    }
+    for (uint32_t i = lane; i < n; i += 64u) {   // indices ascend within a lane: strict < keeps the lowest
+        if (screen && i < ns && !(se2_screen(tree.sh[i], qx, qy, qt) <= thr)) continue;
+        tree.load(i, c);
         const double d = se2_distance(c, q);
         if (d < e.dist) { e.dist = d; e.idx = i; }
     }
     e = exact_wave_reduce(e);
-    if (lane == 0) sh.wave_exact[wave] = e;
-    __syncthreads();
-    e = sh.wave_exact[0];
-#pragma unroll
-    for (int w = 1; w < kSe2Waves; ++w) e = exact_combine(e, sh.wave_exact[w]);
-    nearest = uni(e.idx);
-    const double min_dist = unid(e.dist);
-    const double q_near[3] = {tree[nearest], tree[cap + nearest], tree[2 * cap + nearest]};
+    nearest = e.idx;
+    min_dist = e.dist;
+    tree.load(nearest, q_near);
+}
+
+// cycle stamps of problem 0 (diagnostic instantiation, oxhip_rrt_batch_enable_stamps): DevParams::dbg[0..8] = cycles spent sampling,
+// in the nearest-neighbour search, steering, in the motion check, inserting, in checksum + goal test, in the whole loop; iterations; extends
+template <bool STAMP>
+__device__ __forceinline__ uint64_t se2_clock() { return STAMP ? (uint64_t)__builtin_readcyclecounter() : 0ull; }
+
+// extend() of rrt_connect.rs:121-159 by one wave; 0 = motion invalid, 1 = Advanced, 2 = Reached
+template <bool STAMP>
+__device__ __forceinline__ int se2_extend(const DevParams& p, const double* segs, const Se2Tree& tree, int32_t* parent, uint32_t& n,
+                                          Se2Range& rg, const double q[3], uint32_t& nearest, double q_new[3], const double (*tdiv)[8],
+                                          uint64_t* acc) {
+    const uint32_t lane = threadIdx.x & 63u;
+    double min_dist, q_near[3];
+    const uint64_t t0 = se2_clock<STAMP>();
+    se2_nearest(tree, n, q, rg, lane, nearest, min_dist, q_near);
+    const uint64_t t1 = se2_clock<STAMP>();
     int result;
+    uint32_t nsteps;
     if (min_dist > p.max_distance) {   // rrt_connect.rs:140-147
         se2_interpolate(q_near, q, p.max_distance / min_dist, q_new);
+        // check_motion's step count is ceil(distance(q_near, q_new) / res), and q_new lies max_distance along the geodesic from q_near:
+        // the computed distance is max_distance up to a few roundings of quantities no larger than mag + PI (< 2^-45 (mag + 4) by a
+        // wide margin).  When max_distance / res is farther than that from an integer (adv_slack, in distance units, from the host)
+        // the count is the constant adv_steps, and the square root, the division and the ceil it would take are not evaluated.
+        const bool known = p.se2_adv_steps != 0u && rg.theta_ok && fabsf((float)q[2]) <= kSe2PiUp &&
+                           (double)(rg.mag + fabsf((float)q[0]) + fabsf((float)q[1]) + 4.0f) * 0x1p-45 < p.se2_adv_slack;
+        nsteps = known ? p.se2_adv_steps : num_steps_u32(se2_distance(q_near, q_new), p.res);
         result = 1;
     } else {
         q_new[0] = q[0]; q_new[1] = q[1]; q_new[2] = q[2];
+        nsteps = num_steps_u32(min_dist, p.res);   // distance(q_near, q): the value the scan computed for this very pair
         result = 2;
     }
-    const bool bad = se2_motion_invalid_partial(p, q_near, q_new, tid, kSe2Threads);
-    if (__syncthreads_or(bad ? 1 : 0)) return 0;
-    if (tid == 0) {
-        tree[n] = q_new[0]; tree[cap + n] = q_new[1]; tree[2 * cap + n] = q_new[2];
+    const uint64_t t2 = se2_clock<STAMP>();
+    const bool invalid = se2_motion_invalid_wave(p, segs, q_near, q_new, nsteps, lane, tdiv);
+    if (STAMP) { acc[1] += t1 - t0; acc[2] += t2 - t1; acc[3] += se2_clock<STAMP>() - t2; acc[8] += 1; }
+    if (invalid) return 0;
+    const uint64_t t3 = se2_clock<STAMP>();
+    if (lane == 0) {
+        tree.g[n] = q_new[0]; tree.g[tree.cap + n] = q_new[1]; tree.g[2 * tree.cap + n] = q_new[2];
         parent[n] = (int32_t)nearest;
+        if (n < (uint32_t)kSe2N) tree.sh[n] = make_float4((float)q_new[0], (float)q_new[1], (float)q_new[2], 0.0f);
     }
+    rg.mag = fmaxf(rg.mag, fmaxf(fabsf((float)q_new[0]), fabsf((float)q_new[1])));
+    rg.theta_ok = rg.theta_ok && fabsf((float)q_new[2]) <= kSe2PiUp;
+    // the next scan is this wave's own and LDS is in order per wave (the fence keeps the compiler from moving the store)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     ++n;
-    __syncthreads();
+    if (STAMP) acc[4] += se2_clock<STAMP>() - t3;
     return result;
 }
 
-__global__ __launch_bounds__(kSe2Threads) void rrt_connect_se2_kernel(DevParams p) {
-    const uint32_t prob = blockIdx.x, tid = threadIdx.x;
+// shadow of the first nodes of a tree an earlier launch (or setup) left in HBM; folds them into the screen's range
+__device__ __forceinline__ void se2_shadow_load(const Se2Tree& tree, uint32_t n, uint32_t lane, Se2Range& rg) {
+    float mag = 0.0f;
+    bool ok = true;
+    for (uint32_t i = lane; i < n; i += 64u) {
+        double c[3];
+        tree.load(i, c);
+        const float4 s = make_float4((float)c[0], (float)c[1], (float)c[2], 0.0f);
+        if (i < (uint32_t)kSe2N) tree.sh[i] = s;
+        mag = fmaxf(mag, fmaxf(fabsf(s.x), fabsf(s.y)));
+        ok = ok && fabsf(s.z) <= kSe2PiUp;
+    }
+    mag = __uint_as_float(~wave_min_u32(~__float_as_uint(mag)));   // (maximum of non-negative values through their bit patterns)
+    rg.mag = fmaxf(rg.mag, mag);
+    rg.theta_ok = rg.theta_ok && __ballot(!ok) == 0;
+}
+
+template <bool LDS_SEGS, bool STAMP>
+__global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
+    const uint32_t prob = blockIdx.x, lane = threadIdx.x;
     __shared__ Se2Shared sh;
-    if (p.n_segs <= (uint32_t)kSe2LdsSegs) {   // the checker's table at LDS latency (made visible by the first barrier)
-        for (uint32_t i = tid; i < 4 * p.n_segs; i += kSe2Threads) (&sh.segs[0][0])[i] = p.segs[i];
-        p.segs = &sh.segs[0][0];
+    const double* segs = p.segs;
+    if (LDS_SEGS) {   // the checker's table at LDS latency
+        for (uint32_t i = lane; i < 4 * p.n_segs; i += 64u) (&sh.segs[0][0])[i] = p.segs[i];
+        segs = &sh.segs[0][0];
     }
     ProblemState st = p.state[prob];
     if (st.goal_node >= 0) return;
     const size_t cap = p.cap;
-    double* tree_a = p.tree + (size_t)prob * 3 * cap;
-    double* tree_b = p.tree_b + (size_t)prob * 3 * cap;
+    const Se2Tree tree_a{p.tree + (size_t)prob * 3 * cap, sh.shadow_a, cap};
+    const Se2Tree tree_b{p.tree_b + (size_t)prob * 3 * cap, sh.shadow_b, cap};
     int32_t* par_a = p.parent + (size_t)prob * cap;
     int32_t* par_b = p.parent_b + (size_t)prob * cap;
     const double goal_c[3] = {p.goal_c[(size_t)prob * 3], p.goal_c[(size_t)prob * 3 + 1], p.goal_c[(size_t)prob * 3 + 2]};
@@ -173,17 +464,37 @@ __global__ __launch_bounds__(kSe2Threads) void rrt_connect_se2_kernel(DevParams 
     RngWindow rng;
     rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
     uint32_t na = st.n_nodes, nb = st.n_nodes_b;
+    sh.tdiv[lane >> 3][lane & 7u] = (double)((lane & 7u) + 1u) / (double)((lane >> 3) + 1u);
+    Se2Range rg{0.0f, true};   // a solve call continues the trees an earlier one left in HBM
+    se2_shadow_load(tree_a, na, lane, rg);
+    se2_shadow_load(tree_b, nb, lane, rg);
+    __syncthreads();
     int32_t stop = 1;
+    uint64_t draws = st.draws;   // stream position after the last iteration that ran (the block sampler runs ahead of it)
+    uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const uint64_t t_begin = se2_clock<STAMP>();
     for (uint64_t it = 0; it < p.budget; ++it) {
         if (na >= p.max_nodes || nb >= p.max_nodes) { stop = 2; break; }
         const bool grow_start = na <= nb;   // rrt_connect.rs:249-254
         // sample: random_bool, then x, y, theta by random_range (lo/hi/scale[2] hold the clamped SO(2) bounds)
         double q_rand[3];
-        sample_state<3>(rng, p, 3, goal_c, q_rand);
+        const uint64_t ts = se2_clock<STAMP>();
+        const uint32_t slot = (uint32_t)it & 63u;
+        if (slot == 0u) se2_sample_block(rng, p, goal_c, p.budget - it < 64u ? (uint32_t)(p.budget - it) : 64u, lane, sh);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) q_rand[k] = sh.q[k][slot];
+        draws = sh.pos_after[slot];
+        if (STAMP) acc[0] += se2_clock<STAMP>() - ts;
+        uint64_t t_ext = 0;   // cycles inside extend() this iteration
         uint32_t near_a = 0, near_b = 0;
         double qa[3], qb[3];
-        const int ra = grow_start ? se2_extend(p, sh, tree_a, par_a, cap, na, q_rand, near_a, qa)
-                                  : se2_extend(p, sh, tree_b, par_b, cap, nb, q_rand, near_a, qa);
+        // the tree that grows this iteration and the other one (one copy of extend()'s code serves either role)
+        const Se2Tree t1{grow_start ? tree_a.g : tree_b.g, grow_start ? tree_a.sh : tree_b.sh, cap};
+        const Se2Tree t2{grow_start ? tree_b.g : tree_a.g, grow_start ? tree_b.sh : tree_a.sh, cap};
+        uint32_t n1 = grow_start ? na : nb, n2 = grow_start ? nb : na;
+        const uint64_t te0 = se2_clock<STAMP>();
+        const int ra = se2_extend<STAMP>(p, segs, t1, grow_start ? par_a : par_b, n1, rg, q_rand, near_a, qa, sh.tdiv, acc);
+        t_ext += se2_clock<STAMP>() - te0;
         uint64_t h = fnv_mix(st.checksum, grow_start ? 1ull : 0ull);
         h = fnv_mix(h, (uint64_t)near_a);
 #pragma unroll
@@ -192,40 +503,56 @@ __global__ __launch_bounds__(kSe2Threads) void rrt_connect_se2_kernel(DevParams 
         st.iterations++;
         bool done = false;
         if (ra) {
-            const uint32_t idx_a = (grow_start ? na : nb) - 1;
+            const uint32_t idx_a = n1 - 1;
             if (grow_start && se2_distance(qa, goal_c) <= goal_radius) {   // rrt_connect.rs:271-274
                 st.goal_node = (int32_t)idx_a;
                 st.goal_node_b = -1;
                 done = true;
             } else {
-                const int rb = grow_start ? se2_extend(p, sh, tree_b, par_b, cap, nb, qa, near_b, qb)
-                                          : se2_extend(p, sh, tree_a, par_a, cap, na, qa, near_b, qb);
+                const uint64_t te1 = se2_clock<STAMP>();
+                const int rb = se2_extend<STAMP>(p, segs, t2, grow_start ? par_b : par_a, n2, rg, qa, near_b, qb, sh.tdiv, acc);
+                t_ext += se2_clock<STAMP>() - te1;
                 h = fnv_mix(h, (uint64_t)near_b);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(qb[k]));
                 h = fnv_mix(h, (uint64_t)rb);
                 if (rb == 2) {
-                    const uint32_t idx_b = (grow_start ? nb : na) - 1;
+                    const uint32_t idx_b = n2 - 1;
                     st.goal_node = (int32_t)(grow_start ? idx_a : idx_b);
                     st.goal_node_b = (int32_t)(grow_start ? idx_b : idx_a);
                     done = true;
                 }
             }
         }
+        na = grow_start ? n1 : n2;
+        nb = grow_start ? n2 : n1;
         st.checksum = h;
+        if (STAMP) { acc[5] += se2_clock<STAMP>() - te0 - t_ext; acc[7] += 1; }
         if (done) { stop = 0; break; }
     }
-    if (tid == 0) {
+    if (STAMP && prob == 0 && lane == 0 && p.dbg) {
+        acc[6] = se2_clock<STAMP>() - t_begin;
+        for (int k = 0; k < 9; ++k) p.dbg[k] = acc[k];
+    }
+    if (lane == 0) {
         st.n_nodes = na;
         st.n_nodes_b = nb;
-        st.draws = rng.pos;
+        st.draws = draws;
         st.stop_reason = stop;
         p.state[prob] = st;
     }
 }
 
 void launch_rrt_connect_se2(const DevParams& p, hipStream_t stream) {
-    hipLaunchKernelGGL(rrt_connect_se2_kernel, dim3(p.n_problems), dim3(kSe2Threads), 0, stream, p);
+    const dim3 grid(p.n_problems), block(64);
+    const bool lds = p.n_segs <= (uint32_t)kSe2LdsSegs;
+    if (p.dbg) {   // diagnostic instantiation (cycle stamps of problem 0)
+        if (lds) hipLaunchKernelGGL((rrt_connect_se2_kernel<true, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((rrt_connect_se2_kernel<false, true>), grid, block, 0, stream, p);
+        return;
+    }
+    if (lds) hipLaunchKernelGGL((rrt_connect_se2_kernel<true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((rrt_connect_se2_kernel<false, false>), grid, block, 0, stream, p);
 }
 
 // ---- stand-alone primitives (parity tests of the SO(2) / SE(2) arithmetic and of the checker)
@@ -267,8 +594,7 @@ __global__ __launch_bounds__(256) void se2_check_motion_kernel(DevParams p, cons
     if (m >= n) return;
     const double f[3] = {from[3 * (size_t)m], from[3 * (size_t)m + 1], from[3 * (size_t)m + 2]};
     const double g[3] = {to[3 * (size_t)m], to[3 * (size_t)m + 1], to[3 * (size_t)m + 2]};
-    const bool bad = se2_motion_invalid_partial(p, f, g, lane, 64);
-    const bool any = __ballot(bad) != 0;
+    const bool any = se2_motion_invalid_wave(p, p.segs, f, g, num_steps_u32(se2_distance(f, g), p.res), lane);
     if (lane == 0) out[m] = any ? 0 : 1;
 }
 void launch_se2_check_motion(const DevParams& p, const double* from, const double* to, uint32_t n, uint8_t* out, hipStream_t s) {

@@ -38,10 +38,11 @@ def make_oracle(P, seed, pid, max_nodes=None):
     return o
 
 
-def make_gpu(P, n_problems, seed, first_pid, max_nodes=None):
+def make_gpu(P, n_problems, seed, first_pid, max_nodes=None, debug_flags=0):
     bounds = list(P["bounds_xy"]) + [tuple(P["theta_bounds"])]
     g = capi.RRTBatch(3, bounds, P["max_distance"], P["goal_bias"], n_problems, max_nodes or P["max_nodes"], P["fraction"],
-                      True, seed, first_pid, 0, capi.KERNEL_AUTO, capi.PLANNER_RRT_CONNECT, 0.0, capi.SPACE_SE2)
+                      True, seed, first_pid, 0, capi.KERNEL_AUTO, capi.PLANNER_RRT_CONNECT, 0.0, capi.SPACE_SE2,
+                      debug_flags=debug_flags)
     g.set_segments(segs_of(P), P["clearance"])
     g.setup(P["start"], P["goal"], P["goal_r"])
     return g
@@ -161,3 +162,88 @@ def test_se2_node_cap_and_argument_validation(se2_golden):
         with pytest.raises(capi.OxhipError) as ei:
             capi.RRTBatch(**args)
         assert ei.value.status == status
+
+
+def hexsegs(segs):
+    return [["%016x" % int(bits(np.array([float(v)]))[0]) for v in s] for s in segs]
+
+
+def test_se2_without_the_segment_grid_and_in_chunks(se2_golden):
+    """The grid lookup of the motion check switched off (every state against every segment), and a solve cut into launches of 37
+    iterations (the block sampler starts over inside its 64-iteration blocks): same trees, checksums and paths"""
+    P = se2_golden["soup256"]["params"]
+    ref = make_gpu(P, 12, 21, 40)
+    assert (ref.solve(10 ** 6) == capi.OK).all()
+    c0, gc0 = ref.counts(), ref.goal_counts()
+    plain = make_gpu(P, 12, 21, 40, debug_flags=capi.DEBUG_SE2_NO_SEGMENT_GRID)
+    assert (plain.solve(10 ** 6) == capi.OK).all()
+    chunked = make_gpu(P, 12, 21, 40)
+    for _ in range(4000):
+        st = chunked.solve(37)
+        if (st == capi.OK).all():
+            break
+    assert (st == capi.OK).all()
+    for g in (plain, chunked):
+        c, gc = g.counts(), g.goal_counts()
+        for k in ("nodes", "iterations", "checksum", "goal_node"):
+            assert np.array_equal(c[k], c0[k]), k
+        assert np.array_equal(gc["nodes"], gc0["nodes"]) and np.array_equal(gc["end_node"], gc0["end_node"])
+        for p in (0, 5, 11):
+            assert np.array_equal(bits(g.path(p)), bits(ref.path(p)))
+    for p in (0, 11):
+        o = make_oracle(P, 21, 40 + p)
+        assert o.solve(10 ** 6) == orc.SOLVED
+        assert_same(chunked, p, o)
+
+
+def test_se2_trees_beyond_the_lds_shadow_and_odd_headings(se2_golden):
+    """Both trees grown to 2,000 nodes (the binary32 shadow holds 768: the rest is evaluated exactly, candidates come back from
+    HBM); a start heading outside [-PI, PI] (the screen's heading formula does not apply: every node exactly)"""
+    P = dict(se2_golden["gap"]["params"])
+    box = [(8.0, 4.0, 10.0, 4.0), (8.0, 6.0, 10.0, 6.0), (8.0, 4.0, 8.0, 6.0), (10.0, 4.0, 10.0, 6.0)]
+    P["segments"] = hexsegs(box)
+    g = make_gpu(P, 2, 5, 0, max_nodes=2000)
+    st = g.solve(10 ** 6)
+    c, gc = g.counts(), g.goal_counts()
+    assert (st == capi.ERR_NO_SOLUTION_FOUND).all() and (c["stop_reason"] == capi.STOP_NODES).all()
+    assert int(max(c["nodes"].max(), gc["nodes"].max())) == 2000
+    for p in range(2):
+        o = make_oracle(P, 5, p, max_nodes=2000)
+        assert o.solve(10 ** 6) == orc.NO_SOLUTION_FOUND
+        assert_same(g, p, o, c, gc)
+    Q = dict(se2_golden["soup256"]["params"])
+    Q["start"] = [Q["start"][0], Q["start"][1], 4.0]
+    g = make_gpu(Q, 3, 8, 0)
+    assert (g.solve(10 ** 6) == capi.OK).all()
+    for p in range(3):
+        o = make_oracle(Q, 8, p)
+        assert o.solve(10 ** 6) == orc.SOLVED
+        assert_same(g, p, o)
+
+
+def test_se2_crowded_cells_and_soups_beyond_the_lds_table(se2_golden):
+    """A cell of the lookup grid that more than eight segments reach (its states meet every segment), and a soup of more than
+    256 segments (the table stays in HBM / L2): planner runs and the stand-alone checks against the oracle"""
+    P = dict(se2_golden["soup256"]["params"])
+    base = segs_of(P)
+    rng = np.random.default_rng(12)
+    knot = np.column_stack([5.0 + rng.uniform(-0.05, 0.05, 14), 5.0 + rng.uniform(-0.05, 0.05, 14),
+                            5.0 + rng.uniform(-0.05, 0.05, 14), 5.0 + rng.uniform(-0.05, 0.05, 14)])
+    for segs in (np.vstack([base[:200], knot]), np.vstack([base, knot, base[:60] + 0.013])):
+        Q = dict(P)
+        Q["segments"] = hexsegs(segs)
+        g = make_gpu(Q, 4, 31, 0)
+        st = g.solve(200000)
+        c, gc = g.counts(), g.goal_counts()
+        for p in range(4):
+            o = make_oracle(Q, 31, p)
+            o.solve(200000)
+            assert_same(g, p, o, c, gc)
+        n = 1500
+        a = np.column_stack([rng.uniform(4.5, 5.5, n), rng.uniform(4.5, 5.5, n), rng.uniform(-3, 3, n)])
+        b = a + np.column_stack([rng.normal(0, 0.3, n), rng.normal(0, 0.3, n), rng.normal(0, 1.0, n)])
+        m = g.check_motion(a, b)
+        o = make_oracle(Q, 0, 0)
+        assert 0.02 < m.mean() < 0.98
+        for i in range(n):
+            assert bool(m[i]) == o.check_motion(a[i], b[i])
