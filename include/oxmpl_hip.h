@@ -178,7 +178,9 @@ int32_t oxhip_rrt_batch_set_boxes(oxhip_rrt_batch* b, const double* lo /*[n][dim
 
 /* SE(2) batches only.  The checker of BASELINE.json configs[3]: a disc robot of radius `clearance` among n line
  * segments (ax, ay, bx, by) -- a state is valid iff its (x, y) is farther than `clearance` from every segment
- * (strict; the heading does not enter).  Replaces any earlier segment set. */
+ * (strict; the heading does not enter).  Replaces any earlier segment set.  Also files the segments in a 256 x 256 lookup grid
+ * over the (x, y) bounds on the device (1 MiB; rrt_connect_se2.hip, seg_grid_kernel): the planner's motion checks and
+ * oxhip_rrt_batch_check_motion test a state against its cell's segments only -- the same verdicts, by construction. */
 int32_t oxhip_rrt_batch_set_segments(oxhip_rrt_batch* b, const double* segments /*[n][4]*/, uint32_t n,
                                      double clearance);
 

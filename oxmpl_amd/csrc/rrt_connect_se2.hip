@@ -95,7 +95,7 @@ __device__ __forceinline__ bool segment_hit(const DevParams& p, const double s[3
 // wider (the triangle inequality; the widening and the relative 1e-9 are orders of magnitude above the roundings of
 // point_segment_d2 and of the cell index).  A segment a cell does not list is farther than the clearance from every state in the
 // cell, its test would come out "no hit", and is_valid is the conjunction of those tests: same verdicts, by construction.
-constexpr uint32_t kSegGridG = 128;
+constexpr uint32_t kSegGridG = 256;
 constexpr int kSegSlots = 8;
 constexpr uint32_t kSegNone = 0xFFFFu, kSegOverflow = 0xFFFEu;
 
@@ -199,6 +199,7 @@ struct Se2Shared {
     double tdiv[8][8];              // (s + 1) / n, n = 1 .. 8 (se2_motion_invalid_wave)
 };
 static_assert(sizeof(Se2Shared) <= 40960, "four problems per CU");
+static_assert(kSe2N % 32 == 0, "se2_round reads the shadow four slots of eight lanes at a time");
 
 // Lane-parallel sampling of m <= 64 consecutive iterations (rrt_connect.rs:258-262 + the SE(2) sample_uniform; the scheme of
 // rrt_cells.hip's cells_sample): lane j draws iteration j.  Where its words start depends on how many of the iterations before
@@ -291,10 +292,19 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 constexpr float kSe2PiUp = 3.14159274f;   // fl32(PI), which is > PI
 __device__ __forceinline__ float se2_screen(const float4 s, float qx, float qy, float qt) {
     const float dx = s.x - qx, dy = s.y - qy;
-    const float r = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+    const float r = __builtin_amdgcn_sqrtf(__builtin_fmaf(dy, dy, dx * dx));
     const float a = fabsf(s.z - qt);
-    return r + 0.5f * fminf(a, 6.28318548f - a);
+    return __builtin_fmaf(0.5f, fminf(a, 6.28318548f - a), r);   // (fused or not: the estimate's error bound covers either)
 }
+// smallest and second smallest estimate of a lane and the node with the smallest (the first one: a repeated value shows up as b2 == b1)
+__device__ __forceinline__ void se2_top2(float& b1, float& b2, uint32_t& i1, float d, uint32_t i) {
+    i1 = d < b1 ? i : i1;
+    float m;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(d), "v"(b1), "v"(b2));   // the second smallest of three with b1 <= b2
+    b2 = m;
+    b1 = fminf(b1, d);
+}
+
 
 // Nearest node of rrt_connect.rs:128-136 under the compound distance: the lexicographic (distance, index) minimum over the tree, the
 // distance evaluated exactly as the reference does (sqrt + rem_euclid per node).  Evaluating that for every node is what an
@@ -321,13 +331,11 @@ __device__ __forceinline__ void se2_nearest(const Se2Tree& tree, uint32_t n, con
         for (uint32_t t = 0; t < trips; t += 4u) {
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = lane + ((t + (uint32_t)u) << 6); v[u] = tree.sh[i < ns ? i : 0u]; }
+            for (int u = 0; u < 4; ++u) { const uint32_t i = lane + ((t + (uint32_t)u) << 6); v[u] = tree.sh[i < (uint32_t)kSe2N ? i : 0u]; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 4; ++u) {   // (slots past the tree hold kSe2Far: estimate +inf, never a candidate)
                 const uint32_t i = lane + ((t + (uint32_t)u) << 6);
-                const float d = i < ns ? se2_screen(v[u], qx, qy, qt) : __builtin_inff();
-                if (d < b1) { b2 = b1; b1 = d; i1 = i; }
-                else if (d < b2) b2 = d;
+                se2_top2(b1, b2, i1, i < (uint32_t)kSe2N ? se2_screen(v[u], qx, qy, qt) : __builtin_inff(), i);
             }
         }
         if (!slow && i1 != 0xFFFFFFFFu) tree.load(i1, c);   // in flight across the reduction: almost always it is the lane's only candidate
@@ -372,24 +380,16 @@ __device__ __forceinline__ void se2_nearest(const Se2Tree& tree, uint32_t n, con
     tree.load(nearest, q_near);
 }
 
-// cycle stamps of problem 0 (diagnostic instantiation, oxhip_rrt_batch_enable_stamps): DevParams::dbg[0..8] = cycles spent sampling,
-// in the nearest-neighbour search, steering, in the motion check, inserting, in checksum + goal test, in the whole loop; iterations; extends
+// cycle stamps of problem 0 (diagnostic instantiation, oxhip_rrt_batch_enable_stamps): DevParams::dbg[0..11] = cycles spent sampling,
+// in the rounds' nearest-neighbour searches, their steers, their motion checks, in the whole-wave extends, committing (checksums, inserts,
+// goal tests; includes the whole-wave extends), in the whole loop; iterations; whole-wave extends; rounds; iterations a round committed as failures
 template <bool STAMP>
 __device__ __forceinline__ uint64_t se2_clock() { return STAMP ? (uint64_t)__builtin_readcyclecounter() : 0ull; }
 
-// extend() of rrt_connect.rs:121-159 by one wave; 0 = motion invalid, 1 = Advanced, 2 = Reached
-template <bool STAMP>
-__device__ __forceinline__ int se2_extend(const DevParams& p, const double* segs, const Se2Tree& tree, int32_t* parent, uint32_t& n,
-                                          Se2Range& rg, const double q[3], uint32_t& nearest, double q_new[3], const double (*tdiv)[8],
-                                          uint64_t* acc) {
-    const uint32_t lane = threadIdx.x & 63u;
-    double min_dist, q_near[3];
-    const uint64_t t0 = se2_clock<STAMP>();
-    se2_nearest(tree, n, q, rg, lane, nearest, min_dist, q_near);
-    const uint64_t t1 = se2_clock<STAMP>();
-    int result;
-    uint32_t nsteps;
-    if (min_dist > p.max_distance) {   // rrt_connect.rs:140-147
+// steer of rrt_connect.rs:140-147 and the step count of the motion check that follows; 1 = Advanced, 2 = Reached
+__device__ __forceinline__ int se2_steer(const DevParams& p, const Se2Range& rg, const double q_near[3], const double q[3], double min_dist,
+                                         double q_new[3], uint32_t& nsteps) {
+    if (min_dist > p.max_distance) {
         se2_interpolate(q_near, q, p.max_distance / min_dist, q_new);
         // check_motion's step count is ceil(distance(q_near, q_new) / res), and q_new lies max_distance along the geodesic from q_near:
         // the computed distance is max_distance up to a few roundings of quantities no larger than mag + PI (< 2^-45 (mag + 4) by a
@@ -398,17 +398,16 @@ __device__ __forceinline__ int se2_extend(const DevParams& p, const double* segs
         const bool known = p.se2_adv_steps != 0u && rg.theta_ok && fabsf((float)q[2]) <= kSe2PiUp &&
                            (double)(rg.mag + fabsf((float)q[0]) + fabsf((float)q[1]) + 4.0f) * 0x1p-45 < p.se2_adv_slack;
         nsteps = known ? p.se2_adv_steps : num_steps_u32(se2_distance(q_near, q_new), p.res);
-        result = 1;
-    } else {
-        q_new[0] = q[0]; q_new[1] = q[1]; q_new[2] = q[2];
-        nsteps = num_steps_u32(min_dist, p.res);   // distance(q_near, q): the value the scan computed for this very pair
-        result = 2;
+        return 1;
     }
-    const uint64_t t2 = se2_clock<STAMP>();
-    const bool invalid = se2_motion_invalid_wave(p, segs, q_near, q_new, nsteps, lane, tdiv);
-    if (STAMP) { acc[1] += t1 - t0; acc[2] += t2 - t1; acc[3] += se2_clock<STAMP>() - t2; acc[8] += 1; }
-    if (invalid) return 0;
-    const uint64_t t3 = se2_clock<STAMP>();
+    q_new[0] = q[0]; q_new[1] = q[1]; q_new[2] = q[2];
+    nsteps = num_steps_u32(min_dist, p.res);   // distance(q_near, q): the value the scan computed for this very pair
+    return 2;
+}
+
+// tree.push of rrt_connect.rs:150-157
+__device__ __forceinline__ void se2_insert(const Se2Tree& tree, int32_t* parent, uint32_t& n, Se2Range& rg, uint32_t nearest, const double q_new[3],
+                                           uint32_t lane) {
     if (lane == 0) {
         tree.g[n] = q_new[0]; tree.g[tree.cap + n] = q_new[1]; tree.g[2 * tree.cap + n] = q_new[2];
         parent[n] = (int32_t)nearest;
@@ -421,8 +420,119 @@ __device__ __forceinline__ int se2_extend(const DevParams& p, const double* segs
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     ++n;
-    if (STAMP) acc[4] += se2_clock<STAMP>() - t3;
-    return result;
+}
+
+// extend() of rrt_connect.rs:121-159 by the whole wave, up to the verdict (no insert); 0 = motion invalid, 1 = Advanced, 2 = Reached
+template <bool STAMP>
+__device__ __forceinline__ int se2_extend_try(const DevParams& p, const double* segs, const Se2Tree& tree, uint32_t n, const Se2Range& rg,
+                                              const double q[3], uint32_t& nearest, double q_new[3], const double (*tdiv)[8], uint64_t* acc) {
+    const uint32_t lane = threadIdx.x & 63u;
+    double min_dist, q_near[3];
+    const uint64_t t0 = se2_clock<STAMP>();
+    se2_nearest(tree, n, q, rg, lane, nearest, min_dist, q_near);
+    uint32_t nsteps;
+    const int result = se2_steer(p, rg, q_near, q, min_dist, q_new, nsteps);
+    const bool invalid = se2_motion_invalid_wave(p, segs, q_near, q_new, nsteps, lane, tdiv);
+    if (STAMP) { acc[4] += se2_clock<STAMP>() - t0; acc[8] += 1; }
+    return invalid ? 0 : result;
+}
+
+// ---- eight iterations side by side
+//
+// Four of five iterations end with "motion invalid" (configs[3]), and an iteration that fails changes nothing: not the trees, not which
+// tree grows next.  So the next R <= 8 iterations' first extends are evaluated together against the trees as they are -- eight lanes
+// per iteration: they share the scan of the tree (node i to lane i mod 8), all evaluate the steer, and lane s takes state s of the
+// motion check, walking its cell's segment list -- and committed in order up to and including the first one that succeeds; what was
+// computed for the iterations behind a success is dropped (the tree has changed).  Arithmetic and decisions are se2_extend_try's.
+// An iteration that needs one of the rare paths (a near-tie among the screen's candidates, a tree beyond the shadow, headings outside
+// [-PI, PI], more than eight states, a state outside the grid or in a crowded cell) is flagged `slow`; the round is cut in front of it
+// and it runs through se2_extend_try.
+struct Se2Spec {
+    uint32_t near;
+    double q_new[3];
+    int result;
+    bool slow;
+};
+__device__ __forceinline__ double group8_min_f64(double v) {
+    v = dpp_min_step<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_min_step<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    return dpp_min_step<0x141, 0xf>(v);   // row_half_mirror: every lane holds the minimum of its eight
+}
+__device__ __forceinline__ uint32_t group8_min_u32(uint32_t v) {
+    v = dpp_umin_step<0xB1, 0xf>(v);
+    v = dpp_umin_step<0x4E, 0xf>(v);
+    return dpp_umin_step<0x141, 0xf>(v);
+}
+template <bool STAMP>
+__device__ __forceinline__ void se2_round(const DevParams& p, const double* segs, const Se2Tree& tree, uint32_t n, const Se2Range& rg,
+                                          const Se2Shared& sh, uint32_t slot0, uint32_t R, uint32_t lane, Se2Spec& o, uint64_t* acc) {
+    const uint64_t t0 = se2_clock<STAMP>();
+    const uint32_t grp = lane >> 3, sub = lane & 7u;
+    const uint64_t gm = 0xFFull << (grp * 8u);
+    const uint32_t slot = slot0 + (grp < R ? grp : 0u);
+    const double q[3] = {sh.q[0][slot], sh.q[1][slot], sh.q[2][slot]};
+    const float qx = (float)q[0], qy = (float)q[1], qt = (float)q[2];
+    bool slow = !rg.theta_ok || !(fabsf(qt) <= kSe2PiUp) || n > (uint32_t)kSe2N || (p.n_segs != 0u && p.seg_grid == nullptr);
+    const uint32_t ns = n < (uint32_t)kSe2N ? n : (uint32_t)kSe2N;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this wave's stores first: se2_nearest)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float b1 = __builtin_inff(), b2 = __builtin_inff();
+    uint32_t i1 = 0xFFFFFFFFu;
+    const uint32_t trips = (ns + 7u) >> 3;   // (kSe2N is a multiple of 32: a turn of four never leaves the shadow, whose free slots say kSe2Far)
+    for (uint32_t t = 0; t < trips; t += 4u) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = tree.sh[sub + ((t + (uint32_t)u) << 3)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) se2_top2(b1, b2, i1, se2_screen(v[u], qx, qy, qt), sub + ((t + (uint32_t)u) << 3));
+    }
+    double c[3] = {0.0, 0.0, 0.0};
+    if (i1 != 0xFFFFFFFFu) tree.load(i1, c);
+    const float m = __uint_as_float(group8_min_u32(__float_as_uint(b1)));
+    const float mag = fmaxf(rg.mag, fmaxf(fabsf(qx), fabsf(qy)));
+    const float thr = m + (mag + 3.2f) * (2.02f * 32.0f * 0x1p-24f);
+    slow = slow || (__ballot(b2 <= thr) & gm) != 0;
+    const bool cand = b1 <= thr;
+    Exact e{__builtin_inf(), 0xFFFFFFFFu};
+    if (cand) { e.dist = se2_distance(c, q); e.idx = i1; }
+    const double min_dist = group8_min_f64(e.dist);
+    const uint32_t nearest = group8_min_u32(e.dist == min_dist ? e.idx : 0xFFFFFFFFu);
+    const uint32_t wbits = (uint32_t)((__ballot(cand && e.idx == nearest) >> (grp * 8u)) & 0xFFull);
+    const int wl = (int)(grp * 8u) + (wbits ? __builtin_ctz(wbits) : 0);
+    const double q_near[3] = {__shfl(c[0], wl), __shfl(c[1], wl), __shfl(c[2], wl)};
+    const uint64_t t1 = se2_clock<STAMP>();
+    uint32_t nsteps;
+    const int result = se2_steer(p, rg, q_near, q, min_dist, o.q_new, nsteps);
+    const uint64_t t2 = se2_clock<STAMP>();
+    const uint32_t S = nsteps <= 1u ? 1u : nsteps;
+    bool slow_l = S > 8u, bad = false;
+    if (p.n_segs != 0u && sub < S && !slow && !slow_l) {
+        double x = o.q_new[0], y = o.q_new[1];
+        if (nsteps > 1u) {
+            double xy[2];
+            lerp<2>(q_near, o.q_new, sh.tdiv[nsteps - 1u][sub], xy, 2);
+            x = xy[0]; y = xy[1];
+        }
+        const double fx = (x - p.lo[0]) * p.seg_grid_inv[0], fy = (y - p.lo[1]) * p.seg_grid_inv[1];
+        const double G = (double)p.seg_grid_G;
+        if (fx >= 0.0 && fx < G && fy >= 0.0 && fy < G) {
+            const uint4 ce = reinterpret_cast<const uint4*>(p.seg_grid)[(uint32_t)fy * p.seg_grid_G + (uint32_t)fx];
+            if ((ce.x & 0xFFFFu) == kSegOverflow) slow_l = true;
+            else {
+                const uint32_t w[4] = {ce.x, ce.y, ce.z, ce.w};
+#pragma unroll
+                for (int k = 0; k < kSegSlots; ++k) {
+                    const uint32_t id = (k & 1) ? w[k >> 1] >> 16 : w[k >> 1] & 0xFFFFu;
+                    if (__ballot(id != kSegNone && !bad) == 0) break;   // (uniform: lists are short)
+                    if (id != kSegNone && !bad) bad = !(point_segment_d2(segs, x, y, id) > p.seg_thr);
+                }
+            }
+        } else slow_l = true;
+    }
+    o.slow = slow || (__ballot(slow_l) & gm) != 0;
+    o.result = (__ballot(bad) & gm) != 0 ? 0 : result;
+    o.near = nearest;
+    if (STAMP) { const uint64_t t3 = se2_clock<STAMP>(); acc[1] += t1 - t0; acc[2] += t2 - t1; acc[3] += t3 - t2; acc[9] += 1; }
 }
 
 // shadow of the first nodes of a tree an earlier launch (or setup) left in HBM; folds them into the screen's range
@@ -465,37 +575,74 @@ __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
     rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
     uint32_t na = st.n_nodes, nb = st.n_nodes_b;
     sh.tdiv[lane >> 3][lane & 7u] = (double)((lane & 7u) + 1u) / (double)((lane >> 3) + 1u);
+    for (uint32_t i = lane; i < (uint32_t)kSe2N; i += 64u) sh.shadow_a[i] = sh.shadow_b[i] = make_float4(1e30f, 0.0f, 0.0f, 0.0f);   // kSe2Far
     Se2Range rg{0.0f, true};   // a solve call continues the trees an earlier one left in HBM
     se2_shadow_load(tree_a, na, lane, rg);
     se2_shadow_load(tree_b, nb, lane, rg);
     __syncthreads();
     int32_t stop = 1;
     uint64_t draws = st.draws;   // stream position after the last iteration that ran (the block sampler runs ahead of it)
-    uint64_t acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t t_begin = se2_clock<STAMP>();
-    for (uint64_t it = 0; it < p.budget; ++it) {
+    uint64_t it = 0;
+    while (it < p.budget) {
         if (na >= p.max_nodes || nb >= p.max_nodes) { stop = 2; break; }
         const bool grow_start = na <= nb;   // rrt_connect.rs:249-254
-        // sample: random_bool, then x, y, theta by random_range (lo/hi/scale[2] hold the clamped SO(2) bounds)
-        double q_rand[3];
+        // sample: random_bool, then x, y, theta by random_range (lo/hi/scale[2] hold the clamped SO(2) bounds); 64 iterations at a time
         const uint64_t ts = se2_clock<STAMP>();
         const uint32_t slot = (uint32_t)it & 63u;
         if (slot == 0u) se2_sample_block(rng, p, goal_c, p.budget - it < 64u ? (uint32_t)(p.budget - it) : 64u, lane, sh);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) q_rand[k] = sh.q[k][slot];
-        draws = sh.pos_after[slot];
         if (STAMP) acc[0] += se2_clock<STAMP>() - ts;
-        uint64_t t_ext = 0;   // cycles inside extend() this iteration
-        uint32_t near_a = 0, near_b = 0;
-        double qa[3], qb[3];
         // the tree that grows this iteration and the other one (one copy of extend()'s code serves either role)
         const Se2Tree t1{grow_start ? tree_a.g : tree_b.g, grow_start ? tree_a.sh : tree_b.sh, cap};
         const Se2Tree t2{grow_start ? tree_b.g : tree_a.g, grow_start ? tree_b.sh : tree_a.sh, cap};
         uint32_t n1 = grow_start ? na : nb, n2 = grow_start ? nb : na;
-        const uint64_t te0 = se2_clock<STAMP>();
-        const int ra = se2_extend<STAMP>(p, segs, t1, grow_start ? par_a : par_b, n1, rg, q_rand, near_a, qa, sh.tdiv, acc);
-        t_ext += se2_clock<STAMP>() - te0;
-        uint64_t h = fnv_mix(st.checksum, grow_start ? 1ull : 0ull);
+        // the next R iterations' first extends, side by side
+        uint32_t R = 64u - slot < 8u ? 64u - slot : 8u;
+        if (p.budget - it < (uint64_t)R) R = (uint32_t)(p.budget - it);
+        Se2Spec sp;
+        se2_round<STAMP>(p, segs, t1, n1, rg, sh, slot, R, lane, sp, acc);
+        const uint64_t tc = se2_clock<STAMP>();
+        uint32_t nfast = R;
+        {
+            uint64_t sm = __ballot(sp.slow) & 0x0101010101010101ull;   // lane 8 j speaks for iteration j
+            if (R < 8u) sm &= (1ull << (8u * R)) - 1ull;
+            if (sm) nfast = (uint32_t)__builtin_ctzll(sm) >> 3;
+        }
+        uint32_t near_a = 0, near_b = 0, j = 0;
+        double qa[3], qb[3];
+        int ra = 0;
+        uint64_t h = uni64(st.checksum);   // (wave-uniform by construction: said so, the folds run on the scalar unit)
+        if (nfast == 0u) {   // a rare path: this iteration alone, by the whole wave
+            const double q_rand[3] = {sh.q[0][slot], sh.q[1][slot], sh.q[2][slot]};
+            ra = se2_extend_try<STAMP>(p, segs, t1, n1, rg, q_rand, near_a, qa, sh.tdiv, acc);
+        } else {
+            for (; j < nfast; ++j) {
+                const int src = (int)(8u * j);
+                near_a = (uint32_t)__builtin_amdgcn_readlane((int)sp.near, src);
+                ra = __builtin_amdgcn_readlane(sp.result, src);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) qa[k] = readlane_f64(sp.q_new[k], src);
+                if (ra != 0) break;
+                h = fnv_mix(h, grow_start ? 1ull : 0ull);   // an iteration whose motion was invalid: its checksum, nothing else
+                h = fnv_mix(h, (uint64_t)near_a);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(qa[k]));
+                h = fnv_mix(h, 0ull);
+                st.iterations++;
+            }
+            if (STAMP) { acc[10] += j; }
+            if (j == nfast) {
+                st.checksum = h;
+                draws = sh.pos_after[slot + nfast - 1u];
+                it += nfast;
+                if (STAMP) { acc[5] += se2_clock<STAMP>() - tc; acc[7] += nfast; }
+                continue;
+            }
+        }
+        // iteration it + j: its first extend is (near_a, qa, ra)
+        draws = sh.pos_after[slot + j];
+        h = fnv_mix(h, grow_start ? 1ull : 0ull);
         h = fnv_mix(h, (uint64_t)near_a);
 #pragma unroll
         for (int k = 0; k < 3; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(qa[k]));
@@ -503,15 +650,15 @@ __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
         st.iterations++;
         bool done = false;
         if (ra) {
+            se2_insert(t1, grow_start ? par_a : par_b, n1, rg, near_a, qa, lane);
             const uint32_t idx_a = n1 - 1;
             if (grow_start && se2_distance(qa, goal_c) <= goal_radius) {   // rrt_connect.rs:271-274
                 st.goal_node = (int32_t)idx_a;
                 st.goal_node_b = -1;
                 done = true;
             } else {
-                const uint64_t te1 = se2_clock<STAMP>();
-                const int rb = se2_extend<STAMP>(p, segs, t2, grow_start ? par_b : par_a, n2, rg, qa, near_b, qb, sh.tdiv, acc);
-                t_ext += se2_clock<STAMP>() - te1;
+                const int rb = se2_extend_try<STAMP>(p, segs, t2, n2, rg, qa, near_b, qb, sh.tdiv, acc);
+                if (rb) se2_insert(t2, grow_start ? par_b : par_a, n2, rg, near_b, qb, lane);
                 h = fnv_mix(h, (uint64_t)near_b);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(qb[k]));
@@ -527,12 +674,13 @@ __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
         na = grow_start ? n1 : n2;
         nb = grow_start ? n2 : n1;
         st.checksum = h;
-        if (STAMP) { acc[5] += se2_clock<STAMP>() - te0 - t_ext; acc[7] += 1; }
+        it += j + 1u;
+        if (STAMP) { acc[5] += se2_clock<STAMP>() - tc; acc[7] += j + 1u; }
         if (done) { stop = 0; break; }
     }
     if (STAMP && prob == 0 && lane == 0 && p.dbg) {
         acc[6] = se2_clock<STAMP>() - t_begin;
-        for (int k = 0; k < 9; ++k) p.dbg[k] = acc[k];
+        for (int k = 0; k < 12; ++k) p.dbg[k] = acc[k];
     }
     if (lane == 0) {
         st.n_nodes = na;

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
-@pytest.mark.parametrize("seed,seconds,only", [(3101, 45.0, None), (3102, 40.0, "rrt"), (3103, 25.0, "rrt_star")])
+@pytest.mark.parametrize("seed,seconds,only", [(3101, 45.0, None), (3102, 40.0, "rrt"), (3103, 25.0, "rrt_star"), (3104, 25.0, "se2_connect")])
 def test_fuzz_leg_has_no_mismatch(seed, seconds, only):
     import fuzz_parity
     counts, failures = fuzz_parity.sweep(seconds, seed, only, verbose=False)

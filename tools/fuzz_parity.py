@@ -199,13 +199,20 @@ def case_se2():
     start = [float(rng.uniform(0, 10)), float(rng.uniform(0, 10)), float(rng.uniform(-4, 4))]
     goal = [float(rng.uniform(0, 10)), float(rng.uniform(0, 10)), float(rng.uniform(-4, 4))]
     nprob, iters, max_nodes = int(rng.choice([1, 5])), int(rng.choice([100, 1500])), int(rng.choice([60, 2000]))
+    # (round 3) the lookup grid switched off in a quarter of the cases; the solve cut into launches that end inside a sampled block
+    flags = capi.DEBUG_SE2_NO_SEGMENT_GRID if rng.integers(0, 4) == 0 else 0
+    cuts = sorted(int(v) for v in rng.integers(1, iters, size=int(rng.integers(0, 3))))
     desc = dict(planner="se2", nseg=nseg, th=th, md=md, gb=gb, seed=seed, pid0=pid0, clear=clear, nprob=nprob, iters=iters,
-                max_nodes=max_nodes)
+                max_nodes=max_nodes, flags=flags, cuts=cuts)
     g = capi.RRTBatch(3, [(0.0, 10.0), (0.0, 10.0), th], md, gb, nprob, max_nodes, 0.05, True, seed, pid0, 0, 0,
-                      capi.PLANNER_RRT_CONNECT, 0.0, capi.SPACE_SE2)
+                      capi.PLANNER_RRT_CONNECT, 0.0, capi.SPACE_SE2, debug_flags=flags)
     g.set_segments(segs, clear)
     g.setup(start, goal, 0.4)
-    g.solve(iters)
+    done = 0
+    for cut in cuts + [iters]:
+        if cut > done:
+            g.solve(cut - done)
+            done = cut
     c, gc = g.counts(), g.goal_counts()
     for p in range(nprob):
         o = orc.OracleSE2Connect([(0.0, 10.0), (0.0, 10.0)], th, md, gb, 0.05, max_nodes, seed, pid0 + p)

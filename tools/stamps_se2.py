@@ -14,8 +14,9 @@ g = scenarios.make_se2_batch(sc, P, 10000, 43)
 g.enable_stamps(True)
 g.solve(10 ** 7)
 s = g.stamps()
-names = ["sample", "nearest", "steer", "motion check", "insert", "checksum + goal test", "whole loop", "iterations", "extends"]
-it, ex = int(s[7]), int(s[8])
-print("problem 0 of %d: %d iterations, %d extends, kernel %.3f ms" % (P, it, ex, g.last_timing()["kernel_ms"]))
+names = ["sample", "rounds: nearest", "rounds: steer", "rounds: motion check", "whole-wave extends", "commit (incl. whole-wave extends)", "whole loop"]
+it, ex, rounds, failed = int(s[7]), int(s[8]), int(s[9]), int(s[10])
+print("problem 0 of %d: %d iterations in %d rounds (%d committed as failures by a round), %d whole-wave extends, kernel %.3f ms"
+      % (P, it, rounds, failed, ex, g.last_timing()["kernel_ms"]))
 for k in range(7):
-    print("  %-22s %12d cycles  %8.0f per iteration  %8.0f per extend" % (names[k], int(s[k]), int(s[k]) / max(it, 1), int(s[k]) / max(ex, 1)))
+    print("  %-34s %12d cycles  %8.0f per iteration  %8.0f per round" % (names[k], int(s[k]), int(s[k]) / max(it, 1), int(s[k]) / max(rounds, 1)))
