@@ -181,12 +181,12 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
     dp.space = cfg->space;
     dp.max_distance = cfg->max_distance;
     dp.res = res;
-    if (cfg->space == OXHIP_SPACE_SE2) {   // rrt_connect_se2.hip: the step count of an Advanced extend's motion, when it is safely known
+    if (cfg->planner == OXHIP_PLANNER_RRT_CONNECT) {   // rrt_connect.hip, rrt_connect_se2.hip: the step count of an Advanced extend's motion, when it is safely known
         const double r = cfg->max_distance / res, c = std::ceil(r);
         const double gap = std::fmin(r - (c - 1.0), c - r);
         if (std::isfinite(r) && c >= 1.0 && c < 4294967295.0 && gap > 1e-6) {
-            dp.se2_adv_steps = (uint32_t)c;
-            dp.se2_adv_slack = 0.5 * gap * res;
+            dp.adv_steps = (uint32_t)c;
+            dp.adv_slack = 0.5 * gap * res;
         }
     }
     dp.p_int = bernoulli_p_int(cfg->goal_bias);

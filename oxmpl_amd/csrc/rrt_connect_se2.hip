@@ -395,9 +395,9 @@ __device__ __forceinline__ int se2_steer(const DevParams& p, const Se2Range& rg,
         // the computed distance is max_distance up to a few roundings of quantities no larger than mag + PI (< 2^-45 (mag + 4) by a
         // wide margin).  When max_distance / res is farther than that from an integer (adv_slack, in distance units, from the host)
         // the count is the constant adv_steps, and the square root, the division and the ceil it would take are not evaluated.
-        const bool known = p.se2_adv_steps != 0u && rg.theta_ok && fabsf((float)q[2]) <= kSe2PiUp &&
-                           (double)(rg.mag + fabsf((float)q[0]) + fabsf((float)q[1]) + 4.0f) * 0x1p-45 < p.se2_adv_slack;
-        nsteps = known ? p.se2_adv_steps : num_steps_u32(se2_distance(q_near, q_new), p.res);
+        const bool known = p.adv_steps != 0u && rg.theta_ok && fabsf((float)q[2]) <= kSe2PiUp &&
+                           (double)(rg.mag + fabsf((float)q[0]) + fabsf((float)q[1]) + 4.0f) * 0x1p-45 < p.adv_slack;
+        nsteps = known ? p.adv_steps : num_steps_u32(se2_distance(q_near, q_new), p.res);
         return 1;
     }
     q_new[0] = q[0]; q_new[1] = q[1]; q_new[2] = q[2];

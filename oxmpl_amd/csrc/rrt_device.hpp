@@ -113,8 +113,8 @@ struct DevParams {
     const uint16_t* seg_grid;   // [seg_grid_G^2][8] the segments that can reach each cell of the (x, y) bounds' grid (null: every state meets every segment)
     uint32_t seg_grid_G, seg_grid_pad;
     double seg_grid_inv[2]; // cells per unit length along x, y
-    uint32_t se2_adv_steps, se2_adv_pad;   // ceil(max_distance / res): check_motion's step count for a motion of length max_distance (0: not usable)
-    double se2_adv_slack;   // how far a distance may be from max_distance without changing that count (half the gap to the nearer integer, times res)
+    uint32_t adv_steps, adv_pad;   // RRTConnect: ceil(max_distance / res), check_motion's step count for a motion of length max_distance (0: not usable)
+    double adv_slack;   // how far a distance may be from max_distance without changing that count (half the gap to the nearer integer, times res)
     // RRT* only (rrt_star.hip)
     double* cost;           // [P][cap] cost-to-come of every node (Node::cost, rrt_star.rs:26)
     uint32_t* nb_idx;       // [P][cap] scratch: find_neighbours' result of the current iteration
