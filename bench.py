@@ -32,7 +32,9 @@ the oracle's on that sample, after the grow phase and after the frozen iteration
 `secondary` / `secondary_lanes` / `secondary_f64`: the same steps through the stream kernel, the lane-per-query kernel and the
 all-binary64 resident kernel (checksums of all 1024 problems must equal the main run's).  `secondary_rrt_star`: the RRT* row on the same scene and batch size, 1024 trees grown
 to 10,000 nodes; the checker grows problem 0 with the CPU oracle as well and refuses the line unless parents after rewiring,
-costs and checksum are identical.
+costs and checksum are identical.  `secondary_rrt_connect`: the RRTConnect rows -- BASELINE.json configs[3], SE(2) among
+256 segments, and the R^3 scene of this benchmark -- 1024 problems each, solved to completion by one launch; two problems per row are
+solved by the CPU oracle as well (both trees, checksum, iterations, merged path identical, or no line).
 """
 import argparse
 import json
@@ -202,6 +204,65 @@ def cpu_baseline_and_check(sc, seed, first_id, P, frozen_iters, gpu_after_grow, 
                        "of rrt.rs:170-225); the GPU ran the same iterations of the same problems" % (threads, frozen_iters, threads),
                 verified="GPU node counts, iteration counts and per-iteration checksums == oracle for problems %d..%d after the "
                          "grow phase and after the frozen iterations" % (first_id, first_id + threads - 1))
+
+
+def _se2_oracle(sc4, seed, pid):
+    from oracle import oracle_py as orc
+    o = orc.OracleSE2Connect(sc4["bounds"][:2], sc4["bounds"][2], sc4["max_distance"], sc4["goal_bias"], sc4["lvs_fraction"], 10000, seed, pid)
+    o.set_segments(sc4["segments"], sc4["clearance"])
+    o.setup(sc4["start"], sc4["goal_centre"], sc4["goal_radius"])
+    return o
+
+
+def _connect_oracle(sc, seed, pid):
+    from oracle import oracle_py as orc
+    o = orc.OracleRRTConnect(sc["dim"], sc["bounds"], sc["max_distance"], sc["goal_bias"], sc["lvs_fraction"], 10000, seed, pid)
+    o.set_spheres(*sc["spheres"])
+    o.setup(sc["start"], sc["goal_centre"], sc["goal_radius"])
+    return o
+
+
+def _connect_rows(args, scenarios, capi, sc, P, seed, first_id, device):
+    """the RRTConnect rows (DESIGN.md sections 8 and 11; BASELINE.json configs[3] = SE(2) among 256 segments): 1024 problems solved to
+    completion by one launch each; two problems per row are solved by the CPU oracle too -- both trees, checksum, iteration count and
+    the merged path must be identical, or nothing is printed"""
+    import numpy as np
+    rows = {}
+    sc4 = scenarios.config4()
+    for name, make, make_oracle in (
+            ("se2_256_segments", lambda: scenarios.make_se2_batch(sc4, P, 10000, seed, first_id, device),
+             lambda pid: _se2_oracle(sc4, seed, pid)),
+            ("r3_64_spheres", lambda: scenarios.make_batch(sc, P, 10000, True, seed, first_id, device, 0, capi.PLANNER_RRT_CONNECT),
+             lambda pid: _connect_oracle(sc, seed, pid))):
+        make().solve(10 ** 7)                       # warm-up (code object load)
+        g = make()
+        stc = g.solve(10 ** 7)
+        assert (stc == capi.OK).all()
+        c, gc, ms = g.counts(), g.goal_counts(), g.last_timing()["kernel_ms"]
+        verified = None
+        if not args.no_cpu_baseline:
+            verified = True
+            for pr in (0, P - 1):
+                o = make_oracle(first_id + pr)
+                o.solve(10 ** 7)
+                same = (int(c["iterations"][pr]) == o.iterations and int(c["checksum"][pr]) == o.checksum
+                        and int(c["nodes"][pr]) == o.num_nodes(0) and int(gc["nodes"][pr]) == o.num_nodes(1))
+                for w, (gs, gp) in enumerate((g.tree(pr), g.goal_tree(pr))):
+                    os_, op = o.tree(w)
+                    same = same and np.array_equal(gs.view(np.uint64), os_.view(np.uint64)) and np.array_equal(gp, op)
+                gpath, opath = g.path(pr), o.path()
+                same = same and gpath.shape == opath.shape and np.array_equal(gpath.view(np.uint64), opath.view(np.uint64))
+                if not same:
+                    raise SystemExit("bench.py: RRTConnect (%s) != oracle on problem %d: refusing to report" % (name, first_id + pr))
+        its = int(c["iterations"].sum())
+        rows[name] = {"planner": "RRTConnect (rrt_connect.rs), %d problems to completion" % P, "kernel_ms": ms,
+                      "problems_per_s": P / (ms * 1e-3), "iterations": its, "iterations_per_s": its / (ms * 1e-3),
+                      "slowest_problem_iterations": int(c["iterations"].max()),
+                      "us_per_iteration_of_the_slowest_problem": ms * 1e3 / float(c["iterations"].max()),
+                      "mean_nodes_both_trees": float((c["nodes"] + gc["nodes"]).mean()),
+                      "two_problems_equal_oracle": verified}
+        g.close()
+    return rows
 
 
 def main():
@@ -395,6 +456,10 @@ def main():
                           "problem0_parents_costs_checksum_equal_oracle": verified}
         star.close()
 
+    secondary_connect = None
+    if world == 1 and not args.no_secondary:
+        secondary_connect = _connect_rows(args, scenarios, capi, sc, P, seed, first_id, device)
+
     def check_point():
         """(frozen iterations per problem, GPU counters there): the whole frozen run when the CPU can afford it, else the last
         warm-up boundary"""
@@ -512,6 +577,8 @@ def main():
             out["secondary_f64"] = secondary_f64
         if secondary_star is not None:
             out["secondary_rrt_star"] = secondary_star
+        if secondary_connect:
+            out["secondary_rrt_connect"] = secondary_connect
         if not args.no_cpu_baseline and world == 1:  # the contract: rank 0, N = 1 only
             point = check_point()
             out["cpu_baseline"] = cpu_baseline_and_check(sc, seed, first_id, P, point[0], c, point[1])
