@@ -823,3 +823,50 @@ def test_rrt_connect_batch_matches_oracle():
     with pytest.raises(capi.OxhipError):
         gpu.solve(10, freeze=True)
     gpu.close()
+
+
+def test_rrt_connect_rarely_taken_paths_of_the_one_wave_kernel():
+    """rrt_connect.hip (round 3: one wave per problem): trees beyond the LDS mirror (490 nodes in R^3: the scan continues in HBM
+    behind a drain of this wave's own stores), an obstacle table too large for LDS (generic loads), more than 64 obstacles with
+    boxes among them, motions of more than eight and of more than 64 states (the walked and the lane-per-state motion checks),
+    a solve cut into launches that end inside a sampled block, and R^7 (32 instead of 64 iterations sampled at a time)"""
+    rng = np.random.default_rng(77)
+    # (a) an enclosed goal: both trees run into a node cap of 1,500; 20 spheres + the box walls
+    wall = 0.2
+    a, b = 7.0 - wall, 10.0 + wall   # six slabs around the cube [7, 10]^3, overlapping along its edges (no gap to step through)
+    lo = np.array([[a, a, a], [a, a, 10.0], [a, a, a], [a, 10.0, a], [a, a, a], [10.0, a, a]])
+    hi = np.array([[b, b, 7.0], [b, b, b], [b, 7.0, b], [b, b, b], [7.0, b, b], [b, b, b]])
+    sca = dict(dim=3, bounds=[(0.0, 10.5)] * 3, max_distance=0.5, goal_bias=0.05, lvs_fraction=0.05, start=[0.5] * 3, goal_centre=[8.5] * 3,
+               goal_radius=0.3, spheres=(rng.uniform(1.0, 6.0, (20, 3)), rng.uniform(0.2, 0.6, 20)), boxes=(lo, hi))
+    g = scenarios.make_batch(sca, 2, 1500, True, 9, 0, 0, 0, capi.PLANNER_RRT_CONNECT)
+    st = g.solve(10 ** 6)
+    c, gc = g.counts(), g.goal_counts()
+    assert (st == capi.ERR_NO_SOLUTION_FOUND).all() and (c["stop_reason"] == capi.STOP_NODES).all()
+    assert int(max(c["nodes"].max(), gc["nodes"].max())) == 1500
+    for p in range(2):
+        o = _oracle_connect(sca, 9, p, 1500)
+        assert o.solve(10 ** 6) == orc.NO_SOLUTION_FOUND
+        _assert_same_connect(g, p, o, c, gc)
+    g.close()
+    # (b) 300 small spheres + 40 boxes (1,440 doubles: the table stays in HBM), (c) 70 spheres + 30 boxes (two batches of 64 obstacles),
+    # (d) a fine resolution: 12 states per motion, (e) a very fine one: 1,300 states per motion, (f) R^7
+    def field(ns, nb, dim, r):
+        cen = rng.uniform(1.5, 8.5, (ns, dim))
+        blo = rng.uniform(1.5, 8.0, (nb, dim))
+        return (cen, rng.uniform(0.5 * r, r, ns)), (blo, blo + rng.uniform(0.1, 0.5, (nb, dim)))
+    for ns, nb, dim, r, frac, md, budget in ((300, 40, 3, 0.25, 0.05, 0.5, 4000), (70, 30, 3, 0.5, 0.05, 0.5, 4000), (64, 0, 3, 0.6, 0.02, 0.4, 3000),
+                                             (5, 2, 2, 0.8, 0.0002, 0.37, 600), (40, 10, 7, 1.5, 0.05, 1.1, 3000)):
+        sph, box = field(ns, nb, dim, r)
+        sc = dict(dim=dim, bounds=[(0.0, 10.0)] * dim, max_distance=md, goal_bias=0.1, lvs_fraction=frac, start=[0.7] * dim,
+                  goal_centre=[9.3] * dim, goal_radius=0.4, spheres=sph, boxes=box if nb else None)
+        g = scenarios.make_batch(sc, 3, 3000, True, 5, 100, 0, 0, capi.PLANNER_RRT_CONNECT)
+        done = 0
+        for cut in (37, 101, budget):          # launches ending inside a sampled block
+            g.solve(cut - done)
+            done = cut
+        c, gc = g.counts(), g.goal_counts()
+        for p in range(3):
+            o = _oracle_connect(sc, 5, 100 + p, 3000)
+            o.solve(budget)
+            _assert_same_connect(g, p, o, c, gc)
+        g.close()
