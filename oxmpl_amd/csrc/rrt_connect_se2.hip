@@ -27,11 +27,12 @@ namespace oxhip {
 // same rounded addition.  Everything a planner run produces lies in that window; the rest takes fmod.
 __device__ __forceinline__ double rem_euclid_2pi(double a) {
     const double b = 2.0 * OXHIP_PI;
-    double r;
-    if (a >= 0.0 && a < b) r = a;
-    else if (a >= b && a < 2.0 * b) r = a - b;
-    else if (a < 0.0 && a > -b) r = a;
-    else r = fmod(a, b);
+    // the window, by selects (one uniform branch instead of a chain of divergent ones: this runs several times per extend)
+    double r = a;                                  // a in [0, b), a in (-b, 0), -0.0: fmod's value is a itself
+    r = (a >= b) ? a - b : r;                      // a in [b, 2 b): fmod's value, exactly (Sterbenz)
+    if (__builtin_expect(__ballot(!(a > -b && a < 2.0 * b)) != 0, 0)) {   // outside the window (or NaN): fmod proper
+        if (!(a > -b && a < 2.0 * b)) r = fmod(a, b);
+    }
     return r < 0.0 ? r + b : r;
 }
 __device__ __forceinline__ double so2_normalise(double v) { return rem_euclid_2pi(v + OXHIP_PI) - OXHIP_PI; }
