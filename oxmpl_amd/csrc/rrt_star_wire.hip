@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
     double* cost = p.cost + base;
     int32_t* parent = p.parent + base;
     const StarEntry* pool = p.pool + (size_t)prob * p.pool_share;
-    uint64_t W = p.wire_chk[prob];
+    uint64_t W = uni64(p.wire_chk[prob]);   // (wave-uniform, and said so: the checksum's 64-bit multiplies then run on the scalar unit)
     // an entry as four dwords in registers (a struct copied through a select of two addresses ends up in memory, and the
     // "prefetch" then waits for its own load: measured, 2.2 us per node).  Lanes past the list read a valid address and are masked.
     auto fetch = [](const StarEntry* list, uint32_t idx) { return *reinterpret_cast<const uint4*>(list + idx); };
@@ -477,8 +477,8 @@ __global__ __launch_bounds__(64) void star_wire_kernel(DevParams p) {
                 for (; rm != 0; rm &= rm - 1)   // (a few lanes at most)
                     rew_sum += (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)en.x, __ffsll((unsigned long long)rm) - 1);
             }
-            uint64_t w = fnv_mix(kFnvBasis, (uint64_t)best_j);
-            w = fnv_mix(w, (uint64_t)__double_as_longlong(best_c));
+            uint64_t w = fnv_mix(kFnvBasis, (uint64_t)uni(best_j));
+            w = fnv_mix(w, uni64((uint64_t)__double_as_longlong(best_c)));
             w = fnv_mix(w, rew_cnt);
             w = fnv_mix(w, rew_sum);
             W = W * kFnvPrime + w;
