@@ -24,6 +24,7 @@ GOAL_SAMPLE_CENTRE, GOAL_SAMPLE_UNIFORM_DISC = 0, 1
 DEBUG_PAIR_TO_WHOLE_TREE, DEBUG_AUDIT, DEBUG_ALL_WHOLE_TREE, DEBUG_ONE_LANE_ROUNDS, DEBUG_SHORT_MEMO = 1, 2, 4, 8, 16
 DEBUG_STAR_TWO_PASS, DEBUG_STAR_ONE_SEGMENT = 32, 64
 DEBUG_SE2_NO_SEGMENT_GRID = 128
+DEBUG_SE2_SMALL_LDS = 256
 ABI_VERSION = 2
 STAMP_WORDS = 64
 PLANNER_RRT, PLANNER_RRT_CONNECT, PLANNER_RRT_STAR = 0, 1, 2

@@ -187,26 +187,34 @@ __device__ __forceinline__ bool se2_motion_invalid_wave(const DevParams& p, cons
 }
 
 constexpr int kSe2N = 768;          // nodes of each tree shadowed in LDS (binary32); beyond that every node is evaluated exactly
+constexpr int kSe2NSmall = 512;     // ... in the launches of more problems than the chip has SIMDs (below)
 constexpr int kSe2LdsSegs = 256;    // segments staged in LDS; larger soups are read from HBM / L2
 
-// LDS of one problem = one wave = one workgroup: 36 KB, four problems per CU (one per SIMD)
+// LDS of one problem = one wave = one workgroup.  NS = 768, SEGS = 256: 39 KB, four problems per CU = one per SIMD -- the shape for
+// batches the chip holds at once, where a problem's latency is what counts.  NS = 512, SEGS = 1 (segments from HBM / L2): 22.5 KB,
+// seven per CU -- for larger batches, where the waves of other problems fill the gaps of a latency-bound one (VALU busy is 0.10 at
+// one wave per SIMD).  Same results: the shadow's size only decides how often the exact path runs.
+template <int NS, int SEGS>
 struct Se2Shared {
+    static constexpr int kN = NS;
     uint32_t rng_buf[16][64];
-    float4 shadow_a[kSe2N];         // fl32(x, y, theta) of the start tree's nodes
-    float4 shadow_b[kSe2N];         // ... of the goal tree's
-    double segs[kSe2LdsSegs][4];
+    float4 shadow_a[NS];            // fl32(x, y, theta) of the start tree's nodes
+    float4 shadow_b[NS];            // ... of the goal tree's
+    double segs[SEGS][4];
     double q[3][64];                // the samples of the current block of 64 iterations ...
     uint64_t pos_after[64];         // ... and the stream position after each of them
     double tdiv[8][8];              // (s + 1) / n, n = 1 .. 8 (se2_motion_invalid_wave)
 };
-static_assert(sizeof(Se2Shared) <= 40960, "four problems per CU");
-static_assert(kSe2N % 32 == 0, "se2_round reads the shadow four slots of eight lanes at a time");
+static_assert(sizeof(Se2Shared<kSe2N, kSe2LdsSegs>) <= 40960, "four problems per CU");
+static_assert(sizeof(Se2Shared<kSe2NSmall, 1>) <= 23405, "seven problems per CU");
+static_assert(kSe2N % 32 == 0 && kSe2NSmall % 32 == 0, "se2_round reads the shadow four slots of eight lanes at a time");
 
 // Lane-parallel sampling of m <= 64 consecutive iterations (rrt_connect.rs:258-262 + the SE(2) sample_uniform; the scheme of
 // rrt_cells.hip's cells_sample): lane j draws iteration j.  Where its words start depends on how many of the iterations before
 // it sampled the goal (one word instead of four), so the goal mask is iterated to its fixed point: in round r the first r lanes
 // are right.  Returns false, nothing written, when a range draw was rejected or the window is too short.
-__device__ __forceinline__ bool se2_sample64(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane, Se2Shared& sh) {
+template <class SH>
+__device__ __forceinline__ bool se2_sample64(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane, SH& sh) {
     const uint64_t win_lo = rng.base_blk * 8;
     const uint64_t pos0 = rng.pos;
     if (pos0 < win_lo || pos0 + (uint64_t)m * 4u > win_lo + 512) return false;
@@ -250,7 +258,8 @@ __device__ __forceinline__ bool se2_sample64(RngWindow& rng, const DevParams& p,
     rng.pos = pos0 + (uint32_t)__builtin_amdgcn_readlane((int)(off + cnt), (int)(m - 1));
     return true;
 }
-__device__ __forceinline__ void se2_sample_block(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane, Se2Shared& sh) {
+template <class SH>
+__device__ __forceinline__ void se2_sample_block(RngWindow& rng, const DevParams& p, const double* goal_c, uint32_t m, uint32_t lane, SH& sh) {
     const uint64_t need_hi = rng.pos + (uint64_t)m * 4u;
     if ((rng.pos >> 3) - rng.base_blk >= 64 || need_hi > (rng.base_blk + 64) * 8) {
         rng.base_blk = uni64(rng.pos >> 3);
@@ -276,8 +285,9 @@ __device__ __forceinline__ void se2_sample_block(RngWindow& rng, const DevParams
 // shadow in LDS the scan screens with.
 struct Se2Tree {
     double* g;        // SoA [3][cap] in HBM
-    float4* sh;       // LDS [kSe2N]
+    float4* sh;       // LDS [N]
     size_t cap;
+    uint32_t N;       // nodes the shadow holds
     __device__ __forceinline__ void load(uint32_t i, double c[3]) const { c[0] = g[i]; c[1] = g[cap + i]; c[2] = g[2 * cap + i]; }
 };
 
@@ -316,7 +326,7 @@ __device__ __forceinline__ void se2_top2(float& b1, float& b2, uint32_t& i1, flo
 __device__ __forceinline__ void se2_nearest(const Se2Tree& tree, uint32_t n, const double q[3], const Se2Range& rg, uint32_t lane,
                                             uint32_t& nearest, double& min_dist, double q_near[3]) {
     const float qx = (float)q[0], qy = (float)q[1], qt = (float)q[2];
-    const uint32_t ns = n < (uint32_t)kSe2N ? n : (uint32_t)kSe2N;
+    const uint32_t ns = n < tree.N ? n : tree.N;
     const bool screen = rg.theta_ok && fabsf(qt) <= kSe2PiUp;
     float thr = __builtin_inff();
     bool slow = !screen || n > ns;
@@ -332,11 +342,11 @@ __device__ __forceinline__ void se2_nearest(const Se2Tree& tree, uint32_t n, con
         for (uint32_t t = 0; t < trips; t += 4u) {
             float4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const uint32_t i = lane + ((t + (uint32_t)u) << 6); v[u] = tree.sh[i < (uint32_t)kSe2N ? i : 0u]; }
+            for (int u = 0; u < 4; ++u) { const uint32_t i = lane + ((t + (uint32_t)u) << 6); v[u] = tree.sh[i < tree.N ? i : 0u]; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {   // (slots past the tree hold kSe2Far: estimate +inf, never a candidate)
                 const uint32_t i = lane + ((t + (uint32_t)u) << 6);
-                se2_top2(b1, b2, i1, i < (uint32_t)kSe2N ? se2_screen(v[u], qx, qy, qt) : __builtin_inff(), i);
+                se2_top2(b1, b2, i1, i < tree.N ? se2_screen(v[u], qx, qy, qt) : __builtin_inff(), i);
             }
         }
         if (!slow && i1 != 0xFFFFFFFFu) tree.load(i1, c);   // in flight across the reduction: almost always it is the lane's only candidate
@@ -412,7 +422,7 @@ __device__ __forceinline__ void se2_insert(const Se2Tree& tree, int32_t* parent,
     if (lane == 0) {
         tree.g[n] = q_new[0]; tree.g[tree.cap + n] = q_new[1]; tree.g[2 * tree.cap + n] = q_new[2];
         parent[n] = (int32_t)nearest;
-        if (n < (uint32_t)kSe2N) tree.sh[n] = make_float4((float)q_new[0], (float)q_new[1], (float)q_new[2], 0.0f);
+        if (n < tree.N) tree.sh[n] = make_float4((float)q_new[0], (float)q_new[1], (float)q_new[2], 0.0f);
     }
     rg.mag = fmaxf(rg.mag, fmaxf(fabsf((float)q_new[0]), fabsf((float)q_new[1])));
     rg.theta_ok = rg.theta_ok && fabsf((float)q_new[2]) <= kSe2PiUp;
@@ -464,22 +474,22 @@ __device__ __forceinline__ uint32_t group8_min_u32(uint32_t v) {
     v = dpp_umin_step<0x4E, 0xf>(v);
     return dpp_umin_step<0x141, 0xf>(v);
 }
-template <bool STAMP>
+template <bool STAMP, class SH>
 __device__ __forceinline__ void se2_round(const DevParams& p, const double* segs, const Se2Tree& tree, uint32_t n, const Se2Range& rg,
-                                          const Se2Shared& sh, uint32_t slot0, uint32_t R, uint32_t lane, Se2Spec& o, uint64_t* acc) {
+                                          const SH& sh, uint32_t slot0, uint32_t R, uint32_t lane, Se2Spec& o, uint64_t* acc) {
     const uint64_t t0 = se2_clock<STAMP>();
     const uint32_t grp = lane >> 3, sub = lane & 7u;
     const uint64_t gm = 0xFFull << (grp * 8u);
     const uint32_t slot = slot0 + (grp < R ? grp : 0u);
     const double q[3] = {sh.q[0][slot], sh.q[1][slot], sh.q[2][slot]};
     const float qx = (float)q[0], qy = (float)q[1], qt = (float)q[2];
-    bool slow = !rg.theta_ok || !(fabsf(qt) <= kSe2PiUp) || n > (uint32_t)kSe2N || (p.n_segs != 0u && p.seg_grid == nullptr);
-    const uint32_t ns = n < (uint32_t)kSe2N ? n : (uint32_t)kSe2N;
+    bool slow = !rg.theta_ok || !(fabsf(qt) <= kSe2PiUp) || n > tree.N || (p.n_segs != 0u && p.seg_grid == nullptr);
+    const uint32_t ns = n < tree.N ? n : tree.N;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this wave's stores first: se2_nearest)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     float b1 = __builtin_inff(), b2 = __builtin_inff();
     uint32_t i1 = 0xFFFFFFFFu;
-    const uint32_t trips = (ns + 7u) >> 3;   // (kSe2N is a multiple of 32: a turn of four never leaves the shadow, whose free slots say kSe2Far)
+    const uint32_t trips = (ns + 7u) >> 3;   // (the shadow's size is a multiple of 32: a turn of four never leaves it, and its free slots say "far")
     for (uint32_t t = 0; t < trips; t += 4u) {
         float4 v[4];
 #pragma unroll
@@ -544,7 +554,7 @@ __device__ __forceinline__ void se2_shadow_load(const Se2Tree& tree, uint32_t n,
         double c[3];
         tree.load(i, c);
         const float4 s = make_float4((float)c[0], (float)c[1], (float)c[2], 0.0f);
-        if (i < (uint32_t)kSe2N) tree.sh[i] = s;
+        if (i < tree.N) tree.sh[i] = s;
         mag = fmaxf(mag, fmaxf(fabsf(s.x), fabsf(s.y)));
         ok = ok && fabsf(s.z) <= kSe2PiUp;
     }
@@ -553,10 +563,10 @@ __device__ __forceinline__ void se2_shadow_load(const Se2Tree& tree, uint32_t n,
     rg.theta_ok = rg.theta_ok && __ballot(!ok) == 0;
 }
 
-template <bool LDS_SEGS, bool STAMP>
+template <int NS, bool LDS_SEGS, bool STAMP>
 __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
     const uint32_t prob = blockIdx.x, lane = threadIdx.x;
-    __shared__ Se2Shared sh;
+    __shared__ Se2Shared<NS, LDS_SEGS ? kSe2LdsSegs : 1> sh;
     const double* segs = p.segs;
     if (LDS_SEGS) {   // the checker's table at LDS latency
         for (uint32_t i = lane; i < 4 * p.n_segs; i += 64u) (&sh.segs[0][0])[i] = p.segs[i];
@@ -565,8 +575,8 @@ __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
     ProblemState st = p.state[prob];
     if (st.goal_node >= 0) return;
     const size_t cap = p.cap;
-    const Se2Tree tree_a{p.tree + (size_t)prob * 3 * cap, sh.shadow_a, cap};
-    const Se2Tree tree_b{p.tree_b + (size_t)prob * 3 * cap, sh.shadow_b, cap};
+    const Se2Tree tree_a{p.tree + (size_t)prob * 3 * cap, sh.shadow_a, cap, (uint32_t)NS};
+    const Se2Tree tree_b{p.tree_b + (size_t)prob * 3 * cap, sh.shadow_b, cap, (uint32_t)NS};
     int32_t* par_a = p.parent + (size_t)prob * cap;
     int32_t* par_b = p.parent_b + (size_t)prob * cap;
     const double goal_c[3] = {p.goal_c[(size_t)prob * 3], p.goal_c[(size_t)prob * 3 + 1], p.goal_c[(size_t)prob * 3 + 2]};
@@ -576,7 +586,7 @@ __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
     rng.init(sh.rng_buf, p.seed, p.first_problem_id + prob, st.draws);
     uint32_t na = st.n_nodes, nb = st.n_nodes_b;
     sh.tdiv[lane >> 3][lane & 7u] = (double)((lane & 7u) + 1u) / (double)((lane >> 3) + 1u);
-    for (uint32_t i = lane; i < (uint32_t)kSe2N; i += 64u) sh.shadow_a[i] = sh.shadow_b[i] = make_float4(1e30f, 0.0f, 0.0f, 0.0f);   // kSe2Far
+    for (uint32_t i = lane; i < (uint32_t)NS; i += 64u) sh.shadow_a[i] = sh.shadow_b[i] = make_float4(1e30f, 0.0f, 0.0f, 0.0f);   // "far"
     Se2Range rg{0.0f, true};   // a solve call continues the trees an earlier one left in HBM
     se2_shadow_load(tree_a, na, lane, rg);
     se2_shadow_load(tree_b, nb, lane, rg);
@@ -595,8 +605,8 @@ __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
         if (slot == 0u) se2_sample_block(rng, p, goal_c, p.budget - it < 64u ? (uint32_t)(p.budget - it) : 64u, lane, sh);
         if (STAMP) acc[0] += se2_clock<STAMP>() - ts;
         // the tree that grows this iteration and the other one (one copy of extend()'s code serves either role)
-        const Se2Tree t1{grow_start ? tree_a.g : tree_b.g, grow_start ? tree_a.sh : tree_b.sh, cap};
-        const Se2Tree t2{grow_start ? tree_b.g : tree_a.g, grow_start ? tree_b.sh : tree_a.sh, cap};
+        const Se2Tree t1{grow_start ? tree_a.g : tree_b.g, grow_start ? tree_a.sh : tree_b.sh, cap, (uint32_t)NS};
+        const Se2Tree t2{grow_start ? tree_b.g : tree_a.g, grow_start ? tree_b.sh : tree_a.sh, cap, (uint32_t)NS};
         uint32_t n1 = grow_start ? na : nb, n2 = grow_start ? nb : na;
         // the next R iterations' first extends, side by side
         uint32_t R = 64u - slot < 8u ? 64u - slot : 8u;
@@ -696,12 +706,17 @@ void launch_rrt_connect_se2(const DevParams& p, hipStream_t stream) {
     const dim3 grid(p.n_problems), block(64);
     const bool lds = p.n_segs <= (uint32_t)kSe2LdsSegs;
     if (p.dbg) {   // diagnostic instantiation (cycle stamps of problem 0)
-        if (lds) hipLaunchKernelGGL((rrt_connect_se2_kernel<true, true>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((rrt_connect_se2_kernel<false, true>), grid, block, 0, stream, p);
+        if (lds) hipLaunchKernelGGL((rrt_connect_se2_kernel<kSe2N, true, true>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((rrt_connect_se2_kernel<kSe2N, false, true>), grid, block, 0, stream, p);
         return;
     }
-    if (lds) hipLaunchKernelGGL((rrt_connect_se2_kernel<true, false>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((rrt_connect_se2_kernel<false, false>), grid, block, 0, stream, p);
+    // more problems than SIMDs (or the test switch): the small-LDS shape, seven waves per CU
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    if (p.n_problems > 4u * (uint32_t)cus || (p.dbg_flags & OXHIP_DEBUG_SE2_SMALL_LDS) != 0)
+        hipLaunchKernelGGL((rrt_connect_se2_kernel<kSe2NSmall, false, false>), grid, block, 0, stream, p);
+    else if (lds) hipLaunchKernelGGL((rrt_connect_se2_kernel<kSe2N, true, false>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((rrt_connect_se2_kernel<kSe2N, false, false>), grid, block, 0, stream, p);
 }
 
 // ---- stand-alone primitives (parity tests of the SO(2) / SE(2) arithmetic and of the checker)

@@ -177,13 +177,15 @@ def test_se2_without_the_segment_grid_and_in_chunks(se2_golden):
     c0, gc0 = ref.counts(), ref.goal_counts()
     plain = make_gpu(P, 12, 21, 40, debug_flags=capi.DEBUG_SE2_NO_SEGMENT_GRID)
     assert (plain.solve(10 ** 6) == capi.OK).all()
+    small = make_gpu(P, 12, 21, 40, debug_flags=capi.DEBUG_SE2_SMALL_LDS)   # the shape of batches larger than the chip
+    assert (small.solve(10 ** 6) == capi.OK).all()
     chunked = make_gpu(P, 12, 21, 40)
     for _ in range(4000):
         st = chunked.solve(37)
         if (st == capi.OK).all():
             break
     assert (st == capi.OK).all()
-    for g in (plain, chunked):
+    for g in (plain, small, chunked):
         c, gc = g.counts(), g.goal_counts()
         for k in ("nodes", "iterations", "checksum", "goal_node"):
             assert np.array_equal(c[k], c0[k]), k
@@ -202,15 +204,16 @@ def test_se2_trees_beyond_the_lds_shadow_and_odd_headings(se2_golden):
     P = dict(se2_golden["gap"]["params"])
     box = [(8.0, 4.0, 10.0, 4.0), (8.0, 6.0, 10.0, 6.0), (8.0, 4.0, 8.0, 6.0), (10.0, 4.0, 10.0, 6.0)]
     P["segments"] = hexsegs(box)
-    g = make_gpu(P, 2, 5, 0, max_nodes=2000)
-    st = g.solve(10 ** 6)
-    c, gc = g.counts(), g.goal_counts()
-    assert (st == capi.ERR_NO_SOLUTION_FOUND).all() and (c["stop_reason"] == capi.STOP_NODES).all()
-    assert int(max(c["nodes"].max(), gc["nodes"].max())) == 2000
-    for p in range(2):
-        o = make_oracle(P, 5, p, max_nodes=2000)
-        assert o.solve(10 ** 6) == orc.NO_SOLUTION_FOUND
-        assert_same(g, p, o, c, gc)
+    for flags in (0, capi.DEBUG_SE2_SMALL_LDS):
+        g = make_gpu(P, 2, 5, 0, max_nodes=2000, debug_flags=flags)
+        st = g.solve(10 ** 6)
+        c, gc = g.counts(), g.goal_counts()
+        assert (st == capi.ERR_NO_SOLUTION_FOUND).all() and (c["stop_reason"] == capi.STOP_NODES).all()
+        assert int(max(c["nodes"].max(), gc["nodes"].max())) == 2000
+        for p in range(2):
+            o = make_oracle(P, 5, p, max_nodes=2000)
+            assert o.solve(10 ** 6) == orc.NO_SOLUTION_FOUND
+            assert_same(g, p, o, c, gc)
     Q = dict(se2_golden["soup256"]["params"])
     Q["start"] = [Q["start"][0], Q["start"][1], 4.0]
     g = make_gpu(Q, 3, 8, 0)
