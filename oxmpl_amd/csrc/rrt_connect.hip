@@ -297,12 +297,12 @@ __device__ __forceinline__ int conn_extend(const DevParams& p, const ConnObs& ob
         lerp<D>(q_near, q, t, q_new, dim);
         // check_motion's step count is ceil(distance(q_near, q_new) / res), and q_new lies max_distance along the segment from q_near:
         // the computed distance is max_distance up to a few roundings of quantities no larger than the coordinates in play
-        // (< 2^-45 (mag + 1) by a wide margin).  When max_distance / res is farther than that from an integer (adv_slack, in distance
+        // (< 2^-45 (mag + 1 + max_distance) by a wide margin).  When max_distance / res is farther than that from an integer (adv_slack, in distance
         // units, from the host) the count is the constant adv_steps: no square root, no division, no ceil.
         float qm = 0.0f;
 #pragma unroll
         for (int k = 0; k < D; ++k) if (k < dim) qm = fmaxf(qm, fabsf((float)q[k]));
-        const bool known = p.adv_steps != 0u && (double)(rg.mag + qm + 1.0f) * 0x1p-45 < p.adv_slack;
+        const bool known = p.adv_steps != 0u && ((double)(rg.mag + qm + 1.0f) + p.max_distance) * 0x1p-45 < p.adv_slack;   // (the distance itself is one of those quantities)
         nsteps = known ? p.adv_steps : num_steps_u32(sqrt(dist2<D>(q_near, q_new, dim)), p.res);
         result = 1;
     } else {

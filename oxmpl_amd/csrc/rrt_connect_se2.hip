@@ -403,11 +403,11 @@ __device__ __forceinline__ int se2_steer(const DevParams& p, const Se2Range& rg,
     if (min_dist > p.max_distance) {
         se2_interpolate(q_near, q, p.max_distance / min_dist, q_new);
         // check_motion's step count is ceil(distance(q_near, q_new) / res), and q_new lies max_distance along the geodesic from q_near:
-        // the computed distance is max_distance up to a few roundings of quantities no larger than mag + PI (< 2^-45 (mag + 4) by a
-        // wide margin).  When max_distance / res is farther than that from an integer (adv_slack, in distance units, from the host)
+        // the computed distance is max_distance up to a few roundings of quantities no larger than mag + PI (< 2^-45 (mag + 4 + max_distance)
+        // by a wide margin).  When max_distance / res is farther than that from an integer (adv_slack, in distance units, from the host)
         // the count is the constant adv_steps, and the square root, the division and the ceil it would take are not evaluated.
         const bool known = p.adv_steps != 0u && rg.theta_ok && fabsf((float)q[2]) <= kSe2PiUp &&
-                           (double)(rg.mag + fabsf((float)q[0]) + fabsf((float)q[1]) + 4.0f) * 0x1p-45 < p.adv_slack;
+                           ((double)(rg.mag + fabsf((float)q[0]) + fabsf((float)q[1]) + 4.0f) + p.max_distance) * 0x1p-45 < p.adv_slack;   // (the distance itself is one of those quantities)
         nsteps = known ? p.adv_steps : num_steps_u32(se2_distance(q_near, q_new), p.res);
         return 1;
     }
