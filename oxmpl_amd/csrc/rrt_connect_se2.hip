@@ -475,21 +475,29 @@ __device__ __forceinline__ uint32_t group8_min_u32(uint32_t v) {
     return dpp_umin_step<0x141, 0xf>(v);
 }
 template <bool STAMP, class SH>
-__device__ __forceinline__ void se2_round(const DevParams& p, const double* segs, const Se2Tree& tree, uint32_t n, const Se2Range& rg,
-                                          const SH& sh, uint32_t slot0, uint32_t R, uint32_t lane, Se2Spec& o, uint64_t* acc) {
+__device__ __forceinline__ void se2_round(const DevParams& p, const double* segs, const Se2Tree& t_spec, uint32_t n_spec, const Se2Tree& t_e2,
+                                          uint32_t n_e2, bool pend, const double e2_q[3], const Se2Range& rg, const SH& sh, uint32_t slot0,
+                                          uint32_t groups, uint32_t lane, Se2Spec& o, uint64_t* acc) {
     const uint64_t t0 = se2_clock<STAMP>();
     const uint32_t grp = lane >> 3, sub = lane & 7u;
     const uint64_t gm = 0xFFull << (grp * 8u);
-    const uint32_t slot = slot0 + (grp < R ? grp : 0u);
-    const double q[3] = {sh.q[0][slot], sh.q[1][slot], sh.q[2][slot]};
+    // group 0 of a round with a pending iteration extends the OTHER tree towards that iteration's new node; every other group
+    // extends the tree that grows next towards its own iteration's sample (groups past the round's last repeat the first one's)
+    const bool e2 = pend && grp == 0u;
+    const uint32_t first = pend ? 1u : 0u;
+    const uint32_t slot = slot0 + ((grp >= first && grp < groups) ? grp - first : 0u);
+    const double q[3] = {e2 ? e2_q[0] : sh.q[0][slot], e2 ? e2_q[1] : sh.q[1][slot], e2 ? e2_q[2] : sh.q[2][slot]};
+    const Se2Tree tree{e2 ? t_e2.g : t_spec.g, e2 ? t_e2.sh : t_spec.sh, t_spec.cap, t_spec.N};
+    const uint32_t n = e2 ? n_e2 : n_spec;
     const float qx = (float)q[0], qy = (float)q[1], qt = (float)q[2];
     bool slow = !rg.theta_ok || !(fabsf(qt) <= kSe2PiUp) || n > tree.N || (p.n_segs != 0u && p.seg_grid == nullptr);
     const uint32_t ns = n < tree.N ? n : tree.N;
+    const uint32_t ns_max = n_spec > n_e2 && pend ? (n_spec < tree.N ? n_spec : tree.N) : (pend ? (n_e2 < tree.N ? n_e2 : tree.N) : ns);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (this wave's stores first: se2_nearest)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     float b1 = __builtin_inff(), b2 = __builtin_inff();
     uint32_t i1 = 0xFFFFFFFFu;
-    const uint32_t trips = (ns + 7u) >> 3;   // (the shadow's size is a multiple of 32: a turn of four never leaves it, and its free slots say "far")
+    const uint32_t trips = (ns_max + 7u) >> 3;   // (uniform; the shadow's size is a multiple of 32: a turn of four never leaves it, and the slots past a tree say "far")
     for (uint32_t t = 0; t < trips; t += 4u) {
         float4 v[4];
 #pragma unroll
@@ -595,38 +603,89 @@ __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
     uint64_t draws = st.draws;   // stream position after the last iteration that ran (the block sampler runs ahead of it)
     uint64_t acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const uint64_t t_begin = se2_clock<STAMP>();
-    uint64_t it = 0;
+    uint64_t it = 0, sampled = 0;   // iterations completed; iterations sampled so far (whole blocks of 64)
+    uint64_t h = uni64(st.checksum);   // (wave-uniform by construction: said so, the folds run on the scalar unit)
+    // an iteration whose first extend succeeded waits for the other tree's extend ("pending"): that extend rides in group 0 of the
+    // next round, and the round's other groups evaluate the iterations behind it as if it were going to fail -- nine times in ten
+    // it does (configs[3]), and then nothing has changed before them; when it succeeds they are dropped
+    bool pend = false, pend_gs = false;
+    double pend_q[3] = {0.0, 0.0, 0.0};
+    uint32_t pend_idx = 0;
     while (it < p.budget) {
-        if (na >= p.max_nodes || nb >= p.max_nodes) { stop = 2; break; }
-        const bool grow_start = na <= nb;   // rrt_connect.rs:249-254
-        // sample: random_bool, then x, y, theta by random_range (lo/hi/scale[2] hold the clamped SO(2) bounds); 64 iterations at a time
+        if (!pend && (na >= p.max_nodes || nb >= p.max_nodes)) { stop = 2; break; }
+        const uint64_t it_s = it + (pend ? 1u : 0u);   // the first iteration whose first extend is still to come
+        const bool can_spec = it_s < p.budget && !(na >= p.max_nodes || nb >= p.max_nodes);   // (the node cap is looked at before any draw)
+        const bool gs = na <= nb;   // rrt_connect.rs:249-254, for the iterations from it_s on (until one of them inserts)
         const uint64_t ts = se2_clock<STAMP>();
-        const uint32_t slot = (uint32_t)it & 63u;
-        if (slot == 0u) se2_sample_block(rng, p, goal_c, p.budget - it < 64u ? (uint32_t)(p.budget - it) : 64u, lane, sh);
+        // sample: random_bool, then x, y, theta by random_range (lo/hi/scale[2] hold the clamped SO(2) bounds); 64 iterations at a time
+        if (can_spec && it_s >= sampled) {
+            const uint32_t m = p.budget - sampled < 64u ? (uint32_t)(p.budget - sampled) : 64u;
+            se2_sample_block(rng, p, goal_c, m, lane, sh);
+            sampled += m;
+        }
         if (STAMP) acc[0] += se2_clock<STAMP>() - ts;
-        // the tree that grows this iteration and the other one (one copy of extend()'s code serves either role)
-        const Se2Tree t1{grow_start ? tree_a.g : tree_b.g, grow_start ? tree_a.sh : tree_b.sh, cap, (uint32_t)NS};
-        const Se2Tree t2{grow_start ? tree_b.g : tree_a.g, grow_start ? tree_b.sh : tree_a.sh, cap, (uint32_t)NS};
-        uint32_t n1 = grow_start ? na : nb, n2 = grow_start ? nb : na;
-        // the next R iterations' first extends, side by side
-        uint32_t R = 64u - slot < 8u ? 64u - slot : 8u;
-        if (p.budget - it < (uint64_t)R) R = (uint32_t)(p.budget - it);
+        const uint32_t slot = (uint32_t)it_s & 63u;
+        uint32_t R = 0;
+        if (can_spec) {
+            R = pend ? 7u : 8u;
+            if (64u - slot < R) R = 64u - slot;
+            if (p.budget - it_s < (uint64_t)R) R = (uint32_t)(p.budget - it_s);
+        }
+        const uint32_t first = pend ? 1u : 0u, groups = first + R;
+        // the tree that grows in the iterations from it_s on, and the tree the pending iteration still has to extend
+        const Se2Tree t_spec{gs ? tree_a.g : tree_b.g, gs ? tree_a.sh : tree_b.sh, cap, (uint32_t)NS};
+        const Se2Tree t_e2{pend_gs ? tree_b.g : tree_a.g, pend_gs ? tree_b.sh : tree_a.sh, cap, (uint32_t)NS};
+        uint32_t n_spec = gs ? na : nb, n_e2 = pend_gs ? nb : na;
         Se2Spec sp;
-        se2_round<STAMP>(p, segs, t1, n1, rg, sh, slot, R, lane, sp, acc);
+        se2_round<STAMP>(p, segs, t_spec, n_spec, t_e2, n_e2, pend, pend_q, rg, sh, slot, groups, lane, sp, acc);
         const uint64_t tc = se2_clock<STAMP>();
-        uint32_t nfast = R;
+        uint32_t nfast = groups;
         {
-            uint64_t sm = __ballot(sp.slow) & 0x0101010101010101ull;   // lane 8 j speaks for iteration j
-            if (R < 8u) sm &= (1ull << (8u * R)) - 1ull;
+            uint64_t sm = __ballot(sp.slow) & 0x0101010101010101ull;   // lane 8 g speaks for group g
+            if (groups < 8u) sm &= (1ull << (8u * groups)) - 1ull;
             if (sm) nfast = (uint32_t)__builtin_ctzll(sm) >> 3;
         }
-        uint32_t near_a = 0, near_b = 0, j = 0;
-        double qa[3], qb[3];
+        bool done = false;
+        if (pend) {   // the pending iteration's second extend: group 0, or the whole wave on a rare path
+            uint32_t near_b = 0;
+            double qb[3];
+            int rb;
+            if (nfast == 0u) rb = se2_extend_try<STAMP>(p, segs, t_e2, n_e2, rg, pend_q, near_b, qb, sh.tdiv, acc);
+            else {
+                near_b = (uint32_t)__builtin_amdgcn_readlane((int)sp.near, 0);
+                rb = __builtin_amdgcn_readlane(sp.result, 0);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) qb[k] = readlane_f64(sp.q_new[k], 0);
+            }
+            if (rb) se2_insert(t_e2, pend_gs ? par_b : par_a, n_e2, rg, near_b, qb, lane);
+            h = fnv_mix(h, (uint64_t)near_b);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(qb[k]));
+            h = fnv_mix(h, (uint64_t)rb);
+            if (pend_gs) nb = n_e2; else na = n_e2;
+            if (rb == 2) {   // Reached: rrt_connect.rs:281-305
+                const uint32_t idx_b = n_e2 - 1;
+                st.goal_node = (int32_t)(pend_gs ? pend_idx : idx_b);
+                st.goal_node_b = (int32_t)(pend_gs ? idx_b : pend_idx);
+                done = true;
+            }
+            pend = false;
+            it += 1;
+            if (STAMP) acc[7] += 1;
+            if (done) { stop = 0; break; }
+            if (rb != 0 || nfast == 0u) {   // the iterations behind it were evaluated as if it failed (or a rare path cut the round): start over
+                if (STAMP) acc[5] += se2_clock<STAMP>() - tc;
+                continue;
+            }
+        }
+        // the iterations it, it + 1, ... : groups first .. nfast - 1 hold their first extends
+        uint32_t near_a = 0, j = first;
+        double qa[3];
         int ra = 0;
-        uint64_t h = uni64(st.checksum);   // (wave-uniform by construction: said so, the folds run on the scalar unit)
-        if (nfast == 0u) {   // a rare path: this iteration alone, by the whole wave
+        if (nfast <= first) {   // a rare path (first == 0 here: the pending case has left above): this iteration alone, by the whole wave
+            if (R == 0u) continue;   // (nothing to run: the loop's head decides)
             const double q_rand[3] = {sh.q[0][slot], sh.q[1][slot], sh.q[2][slot]};
-            ra = se2_extend_try<STAMP>(p, segs, t1, n1, rg, q_rand, near_a, qa, sh.tdiv, acc);
+            ra = se2_extend_try<STAMP>(p, segs, t_spec, n_spec, rg, q_rand, near_a, qa, sh.tdiv, acc);
         } else {
             for (; j < nfast; ++j) {
                 const int src = (int)(8u * j);
@@ -635,60 +694,49 @@ __global__ __launch_bounds__(64) void rrt_connect_se2_kernel(DevParams p) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) qa[k] = readlane_f64(sp.q_new[k], src);
                 if (ra != 0) break;
-                h = fnv_mix(h, grow_start ? 1ull : 0ull);   // an iteration whose motion was invalid: its checksum, nothing else
+                h = fnv_mix(h, gs ? 1ull : 0ull);   // an iteration whose motion was invalid: its checksum, nothing else
                 h = fnv_mix(h, (uint64_t)near_a);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(qa[k]));
                 h = fnv_mix(h, 0ull);
                 st.iterations++;
             }
-            if (STAMP) { acc[10] += j; }
+            if (STAMP) acc[10] += j - first;
             if (j == nfast) {
-                st.checksum = h;
-                draws = sh.pos_after[slot + nfast - 1u];
-                it += nfast;
-                if (STAMP) { acc[5] += se2_clock<STAMP>() - tc; acc[7] += nfast; }
+                draws = sh.pos_after[slot + (nfast - first) - 1u];
+                it += nfast - first;
+                if (STAMP) { acc[5] += se2_clock<STAMP>() - tc; acc[7] += nfast - first; }
                 continue;
             }
         }
-        // iteration it + j: its first extend is (near_a, qa, ra)
-        draws = sh.pos_after[slot + j];
-        h = fnv_mix(h, grow_start ? 1ull : 0ull);
+        // iteration it + (j - first): its first extend is (near_a, qa, ra)
+        it += j - first;
+        if (STAMP) acc[7] += j - first;
+        draws = sh.pos_after[slot + (j - first)];
+        h = fnv_mix(h, gs ? 1ull : 0ull);
         h = fnv_mix(h, (uint64_t)near_a);
 #pragma unroll
         for (int k = 0; k < 3; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(qa[k]));
         h = fnv_mix(h, (uint64_t)ra);
         st.iterations++;
-        bool done = false;
-        if (ra) {
-            se2_insert(t1, grow_start ? par_a : par_b, n1, rg, near_a, qa, lane);
-            const uint32_t idx_a = n1 - 1;
-            if (grow_start && se2_distance(qa, goal_c) <= goal_radius) {   // rrt_connect.rs:271-274
-                st.goal_node = (int32_t)idx_a;
-                st.goal_node_b = -1;
-                done = true;
-            } else {
-                const int rb = se2_extend_try<STAMP>(p, segs, t2, n2, rg, qa, near_b, qb, sh.tdiv, acc);
-                if (rb) se2_insert(t2, grow_start ? par_b : par_a, n2, rg, near_b, qb, lane);
-                h = fnv_mix(h, (uint64_t)near_b);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) h = fnv_mix(h, (uint64_t)__double_as_longlong(qb[k]));
-                h = fnv_mix(h, (uint64_t)rb);
-                if (rb == 2) {
-                    const uint32_t idx_b = n2 - 1;
-                    st.goal_node = (int32_t)(grow_start ? idx_a : idx_b);
-                    st.goal_node_b = (int32_t)(grow_start ? idx_b : idx_a);
-                    done = true;
-                }
-            }
+        if (ra == 0) { it += 1; if (STAMP) { acc[5] += se2_clock<STAMP>() - tc; acc[7] += 1; } continue; }
+        se2_insert(t_spec, gs ? par_a : par_b, n_spec, rg, near_a, qa, lane);
+        if (gs) na = n_spec; else nb = n_spec;
+        if (gs && se2_distance(qa, goal_c) <= goal_radius) {   // rrt_connect.rs:271-274
+            st.goal_node = (int32_t)(n_spec - 1);
+            st.goal_node_b = -1;
+            it += 1;
+            stop = 0;
+            break;
         }
-        na = grow_start ? n1 : n2;
-        nb = grow_start ? n2 : n1;
-        st.checksum = h;
-        it += j + 1u;
-        if (STAMP) { acc[5] += se2_clock<STAMP>() - tc; acc[7] += j + 1u; }
-        if (done) { stop = 0; break; }
+        pend = true;
+        pend_gs = gs;
+        pend_idx = n_spec - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pend_q[k] = qa[k];
+        if (STAMP) acc[5] += se2_clock<STAMP>() - tc;
     }
+    st.checksum = h;
     if (STAMP && prob == 0 && lane == 0 && p.dbg) {
         acc[6] = se2_clock<STAMP>() - t_begin;
         for (int k = 0; k < 12; ++k) p.dbg[k] = acc[k];
