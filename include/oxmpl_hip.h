@@ -101,7 +101,7 @@ typedef enum oxhip_debug_flag {
     OXHIP_DEBUG_SHORT_MEMO = 16,          /* rrt_lanes.hip: the memoized answer expires after 8 inserts instead of (ring - 64) */
     OXHIP_DEBUG_STAR_TWO_PASS = 32,       /* rrt_star_wire.hip: neighbour lists by a second search instead of the counting pass's chunks */
     OXHIP_DEBUG_STAR_ONE_SEGMENT = 64,    /* rrt_star_wire.hip: one edge-check segment, no overlap with the wiring stream */
-    OXHIP_DEBUG_SE2_NO_SEGMENT_GRID = 128,/* rrt_connect_se2.hip: every interpolated state is tested against every segment (no grid lookup) */
+    OXHIP_DEBUG_SE2_NO_SEGMENT_GRID = 128,/* rrt_connect_se2.hip / rrt_connect.hip: every interpolated state is tested against every segment / sphere (no grid lookup) */
     OXHIP_DEBUG_SE2_SMALL_LDS = 256       /* rrt_connect_se2.hip: the shape for batches larger than the chip (512-node shadows, segments from HBM / L2) whatever the batch size */
 } oxhip_debug_flag;
 

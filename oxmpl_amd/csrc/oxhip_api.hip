@@ -42,6 +42,8 @@ struct oxhip_rrt_batch {
     DevBuf<double> tree_b;   // RRTConnect goal trees
     DevBuf<double> segs;            // SE(2): segment soup
     DevBuf<uint16_t> seg_grid;      // ... and the cells' segment lists (rrt_connect_se2.hip, seg_grid_kernel)
+    DevBuf<uint64_t> conn_grid;     // RRTConnect in R^2 / R^3: the spheres that reach each cell of the bounds' grid (rrt_connect.hip)
+    DevBuf<double> conn_filt;
     DevBuf<double> cost, nb_dist;   // RRT*: cost-to-come, neighbour scratch
     // RRT*: W of the checksum; the decoupled design's buffers (rrt_star_wire.hip)
     DevBuf<uint64_t> wire_chk;
@@ -514,6 +516,32 @@ int32_t oxhip_rrt_batch_setup(oxhip_rrt_batch* b, const double* starts, const do
 static int32_t refresh_filter(oxhip_rrt_batch* b) {
     if (!b->filt_dirty) return OXHIP_OK;
     const uint32_t n = b->dp.n_spheres, dim = b->cfg.dim;
+    if (b->cfg.planner == OXHIP_PLANNER_RRT_CONNECT && b->cfg.space == OXHIP_SPACE_REAL_VECTOR) {
+        // rrt_connect.hip's motion check looks a state's spheres up (R^2 / R^3, up to 64 spheres, finite bounds): bit j of a cell's
+        // mask = sphere j reaches the cell's box (sphere_grid_kernel: squared distance centre - box, the box taken 2^-9 of a cell
+        // wider, compared with the sphere's own validity threshold and a relative 1e-9 of slack).  A sphere that is not listed
+        // contains no state of the cell: its test would say "no hit".
+        b->dp.sph_grid = nullptr;
+        bool ok = (dim == 2 || dim == 3) && n >= 1 && n <= 64 && (b->cfg.debug_flags & OXHIP_DEBUG_SE2_NO_SEGMENT_GRID) == 0;
+        for (uint32_t k = 0; ok && k < dim; ++k) ok = std::isfinite(b->dp.lo[k]) && std::isfinite(b->dp.hi[k]) && b->dp.hi[k] > b->dp.lo[k];
+        if (ok) {
+            const uint32_t G = sphere_grid_side(dim);
+            const size_t cells = dim == 2 ? (size_t)G * G : (size_t)G * G * G;
+            if (b->conn_grid.n != cells) HIP_TRY(b->conn_grid.alloc(cells));
+            std::vector<double> f(n);
+            for (uint32_t j = 0; j < n; ++j) {
+                const double t = sqrt_le_threshold(b->sph_radii[j]);   // valid iff d2 > t
+                f[j] = std::isfinite(t) ? (t > 0.0 ? t * (1.0 + 1e-9) : t) : t;
+            }
+            int32_t st = upload(b->conn_filt, f, b->stream);
+            if (st != OXHIP_OK) return st;
+            b->dp.sph_grid_G = G;
+            launch_sphere_grid(b->dp, b->conn_grid.p, b->conn_filt.p, b->stream);
+            b->dp.sph_grid = b->conn_grid.p;
+        }
+        b->filt_dirty = false;
+        return OXHIP_OK;
+    }
     double maxabs = 1.0;
     for (uint32_t k = 0; k < 2 * dim; ++k) maxabs = std::fmax(maxabs, std::fabs(b->cfg.bounds[k]));
     for (double v : b->starts) maxabs = std::fmax(maxabs, std::fabs(v));

@@ -14,7 +14,7 @@
 
 namespace oxhip {
 
-constexpr int kConnLdsBytes = 23552;   // LDS for the two trees of one problem (the whole workgroup: <= 40 KB, four per CU)
+constexpr int kConnLdsBytes = 23040;   // LDS for the two trees of one problem (the whole workgroup: <= 40 KB, four per CU)
 
 // cycle stamps of problem 0 (tools/build_variant.sh with -DOXHIP_CONN_STAMPS + oxhip_rrt_batch_enable_stamps; not in the product build):
 // dbg[0..8] = cycles sampling, in the nearest-neighbour search, steering, in the motion check, -, in checksum + insert + goal test, in the
@@ -35,6 +35,7 @@ struct ConnShared {
     uint64_t pos_after[64];       // ... and the stream position after each of them
     double tree_a[D][N], tree_b[D][N];
     ObsLds obs;
+    double tdiv[8][8];            // (s + 1) / n, n = 1 .. 8: the interpolation parameters of motions of up to eight states
 };
 
 // One tree: its first N nodes mirrored in LDS ([k][i], conflict-free for the strided scan), all of it in HBM.
@@ -189,6 +190,10 @@ struct ConnObs {
     const double* lo;    // [dim][nb]
     const double* hi;    // [dim][nb]
     uint32_t ns, nb;
+    const uint64_t* grid;   // R^2 / R^3, up to 64 spheres: bit j of a cell's word = sphere j reaches the cell (DevParams::sph_grid; null: none)
+    uint32_t G;
+    double ginv[3];         // cells per unit length
+    const double (*tdiv)[8];
 };
 
 // rrt_connect.rs:166-189 for one wave; returns the wave-uniform verdict "some tested state is invalid".  Up to 64 states: the
@@ -202,6 +207,41 @@ __device__ __forceinline__ bool conn_motion_invalid(const ConnObs& ob, const Dev
     if (nobs == 0) return false;
     const uint32_t S = nsteps <= 1u ? 1u : nsteps;   // states tested: `to` alone, or steps 1 ..= nsteps
     const double dn = (double)nsteps;
+    if ((D == 2 || D == 3) && ob.grid && ob.nb == 0u && S <= 8u) {
+        // the usual case in R^2 / R^3: eight lanes per state, the state's spheres looked up in the grid (a state outside the bounds:
+        // every sphere); lane k of a state takes the listed spheres j = k mod 8 -- almost always none or one
+        const uint32_t sidx = lane >> 3, k = lane & 7u;
+        bool bad = false;
+        if (sidx < S) {
+            double st[D];
+            if (nsteps > 1u) lerp<D>(from, to, ob.tdiv[nsteps - 1u][sidx], st, dim);
+            else {
+#pragma unroll
+                for (int c = 0; c < D; ++c) st[c] = to[c];
+            }
+            bool inside = true;
+            uint32_t ci[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                const double f = (st[c] - p.lo[c]) * ob.ginv[c];
+                inside = inside && f >= 0.0 && f < (double)ob.G;   // (NaN: outside)
+                ci[c] = inside ? (uint32_t)f : 0u;
+            }
+            uint64_t m = ob.grid[D == 3 ? (ci[2] * ob.G + ci[1]) * ob.G + ci[0] : ci[1] * ob.G + ci[0]];
+            if (!inside) m = ~0ull;
+            if (ob.ns < 64u) m &= (1ull << ob.ns) - 1ull;
+            m &= 0x0101010101010101ull << k;
+            while (m != 0) {
+                const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1ull;
+                double cj[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) cj[c] = ob.c[(size_t)c * ob.ns + j];
+                bad = bad || !(dist2<D>(cj, st, dim) > ob.thr[j]);   // (obstacle_hit's operand order: centre - state)
+            }
+        }
+        return __ballot(bad) != 0;
+    }
     if (S <= 64u) {
         const double tl = (double)(lane + 1u) / dn;
         for (uint32_t j0 = 0; j0 < nobs; j0 += 64u) {
@@ -362,7 +402,12 @@ __global__ __launch_bounds__(64) void rrt_connect_kernel(DevParams p) {
     const uint32_t prob = blockIdx.x, lane = threadIdx.x;
     __shared__ ConnShared<D> sh;
     static_assert(sizeof(ConnShared<D>) <= 40960, "four problems per CU");
-    ConnObs ob{p.sph_c, p.sph_thr, p.box_lo, p.box_hi, p.n_spheres, p.n_boxes};
+    ConnObs ob{p.sph_c, p.sph_thr, p.box_lo, p.box_hi, p.n_spheres, p.n_boxes, (D == 2 || D == 3) ? p.sph_grid : nullptr, p.sph_grid_G, {0.0, 0.0, 0.0}, sh.tdiv};
+    if (ob.grid) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if (k < dim) ob.ginv[k] = (double)ob.G / (p.hi[k] - p.lo[k]);
+    }
+    sh.tdiv[lane >> 3][lane & 7u] = (double)((lane & 7u) + 1u) / (double)((lane >> 3) + 1u);
     if (OBS_LDS) {   // the table at LDS latency, through typed pointers (stage_obstacles' layout; the barrier below covers it)
         double* c = sh.obs.data;
         double* thr = c + (size_t)dim * ob.ns;

@@ -791,6 +791,14 @@ def test_rrt_connect_batch_matches_oracle():
     for p, o in enumerate(planners):
         assert o.solve(100000) == orc.SOLVED
         _assert_same_connect(gpu, p, o, c, gc)
+    # the same batch without the sphere lookup grid of the motion check (every state against every sphere): identical counters
+    plain = scenarios.make_batch(sc, P, 10000, True, 42, 500, 0, 0, capi.PLANNER_RRT_CONNECT, debug_flags=capi.DEBUG_SE2_NO_SEGMENT_GRID)
+    assert (plain.solve(100000) == capi.OK).all()
+    cp, gcp = plain.counts(), plain.goal_counts()
+    for k in ("nodes", "iterations", "checksum", "goal_node"):
+        assert np.array_equal(c[k], cp[k]), k
+    assert np.array_equal(gc["nodes"], gcp["nodes"])
+    plain.close()
     gpu.close()
     # a 5-D problem with boxes + spheres on the runtime-dim kernel, goal_bias 0.3
     rng = np.random.default_rng(4)
