@@ -132,18 +132,27 @@ __device__ __forceinline__ void conn_sample_block(RngWindow& rng, const DevParam
     }
 }
 
-// nearest node of rrt_connect.rs:128-136: d2 compare with second-smallest tracking, exact post-sqrt fallback on a near-tie
+// nearest node of rrt_connect.rs:128-136: d2 compare with second-smallest tracking, exact post-sqrt fallback on a near-tie.  A lane
+// keeps the coordinates of its own best node, and q_near is read out of the winning lane's registers (no second trip to the tree; the
+// LDS range and the HBM range of a tree are walked by separate loops: one loop over a select of the two addresses compiles to flat loads).
 template <int D>
 __device__ __forceinline__ void conn_nearest(const ConnTree<D>& tree, int dim, uint32_t n, const double q[D], uint32_t lane, uint32_t& nearest,
                                              double& min_dist, double q_near[D]) {
     constexpr uint32_t N = (uint32_t)ConnTree<D>::N;
     const uint32_t nl = n < N ? n : N;
     Best best = best_init();
+    double bc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) bc[k] = 0.0;
     for (uint32_t i = lane; i < nl; i += 64u) {   // indices ascend within a lane: strict < keeps the lowest
         double c[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree.l[k][i];
-        best_push(best, dist2<D>(c, q, dim), i);
+        const double d2 = dist2<D>(c, q, dim);
+        const bool lt = d2 < best.b1;
+        best_push(best, d2, i);
+#pragma unroll
+        for (int k = 0; k < D; ++k) if (k < dim) bc[k] = lt ? c[k] : bc[k];
     }
     if (n > N) {   // beyond the mirror: this wave's own stores, drained first
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -152,34 +161,53 @@ __device__ __forceinline__ void conn_nearest(const ConnTree<D>& tree, int dim, u
             double c[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree.g[(size_t)k * tree.cap + i];
-            best_push(best, dist2<D>(c, q, dim), i);
+            const double d2 = dist2<D>(c, q, dim);
+            const bool lt = d2 < best.b1;
+            best_push(best, d2, i);
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k < dim) bc[k] = lt ? c[k] : bc[k];
         }
     }
+    const uint32_t mine = best.i1;
     best = best_wave_reduce(best);
-    if (best_ambiguous(best)) {
+    uint32_t mine_x = mine;
+    if (!best_ambiguous(best)) {
+        nearest = uni(best.i1);
+        min_dist = sqrt(best.b1);
+    } else {   // the reference's own comparison: post-sqrt distances, ascending index
         Exact e{__builtin_inf(), 0xFFFFFFFFu};
-        for (uint32_t i = lane; i < n; i += 64u) {
+        for (uint32_t i = lane; i < nl; i += 64u) {
             double c[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) if (k < dim) c[k] = i < N ? tree.l[k][i < N ? i : 0u] : tree.g[(size_t)k * tree.cap + i];
+            for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree.l[k][i];
             const double d = sqrt(dist2<D>(c, q, dim));
-            if (d < e.dist) { e.dist = d; e.idx = i; }
+            const bool lt = d < e.dist;
+            e.dist = lt ? d : e.dist;
+            e.idx = lt ? i : e.idx;
+#pragma unroll
+            for (int k = 0; k < D; ++k) if (k < dim) bc[k] = lt ? c[k] : bc[k];
         }
+        if (n > N) {
+            for (uint32_t i = N + lane; i < n; i += 64u) {
+                double c[D];
+#pragma unroll
+                for (int k = 0; k < D; ++k) if (k < dim) c[k] = tree.g[(size_t)k * tree.cap + i];
+                const double d = sqrt(dist2<D>(c, q, dim));
+                const bool lt = d < e.dist;
+                e.dist = lt ? d : e.dist;
+                e.idx = lt ? i : e.idx;
+#pragma unroll
+                for (int k = 0; k < D; ++k) if (k < dim) bc[k] = lt ? c[k] : bc[k];
+            }
+        }
+        mine_x = e.idx;
         e = exact_wave_reduce(e);
-        nearest = e.idx;
+        nearest = uni(e.idx);
         min_dist = e.dist;
-    } else {
-        nearest = best.i1;
-        min_dist = sqrt(best.b1);
     }
-    nearest = uni(nearest);
-    if (nearest < N) {
+    const int L = __builtin_ctzll(__ballot(mine_x == nearest) | (1ull << 63));   // the lane that holds the winner (a node belongs to one lane)
 #pragma unroll
-        for (int k = 0; k < D; ++k) if (k < dim) q_near[k] = tree.l[k][nearest];
-    } else {
-#pragma unroll
-        for (int k = 0; k < D; ++k) if (k < dim) q_near[k] = tree.g[(size_t)k * tree.cap + nearest];
-    }
+    for (int k = 0; k < D; ++k) if (k < dim) q_near[k] = conn_readlane_f64(bc[k], L);
 }
 
 // The obstacle table as the motion check reads it: staged in LDS (OBS_LDS: a typed LDS pointer -- a DevParams field that was

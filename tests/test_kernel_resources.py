@@ -217,3 +217,36 @@ def test_cells_headline_kernel_keeps_its_shape(cells_asm):
     assert gbody.count("buffer_wbl2") <= 6, gbody.count("buffer_wbl2")
     # the resolver's exact work is unfused binary64
     assert fbody.count("v_mul_f64") > 50 and fbody.count("v_add_f64") > 50
+
+
+@pytest.fixture(scope="module")
+def connect_asm(tmp_path_factory):
+    d = tmp_path_factory.mktemp("asm_connect")
+    out = {}
+    for src in ("rrt_connect.hip", "rrt_connect_se2.hip"):
+        path = str(d / (src[:-4] + ".s"))
+        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                               "-S", "--cuda-device-only", "-o", path, os.path.join(CSRC, src)], stderr=subprocess.DEVNULL)
+        out[src] = open(path).read()
+    return out
+
+
+def test_rrtconnect_kernels_keep_one_wave_per_simd(connect_asm):
+    """rrt_connect.hip / rrt_connect_se2.hip (round 3): one wave per problem, four problems per CU -- 40 KB of LDS at most (the SE(2)
+    shape for large batches: seven per CU), no scratch (a q_new[lane] once became a scratch array), and the tree / segment / sphere
+    tables are read through LDS or global instructions, never flat ones (a select of an LDS and a global address)"""
+    se2 = {k: v for k, v in _kernels(connect_asm["rrt_connect_se2.hip"]).items() if "rrt_connect_se2_kernel" in k}
+    assert len(se2) == 5   # (768, LDS table) x {product, stamped}, (768, HBM table) x {product, stamped}, (512, HBM table)
+    for name, m in se2.items():
+        assert m["max_flat_workgroup_size"] == 64 and m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)
+        assert m["group_segment_fixed_size"] <= (23405 if "ILi512E" in name else 40960), (name, m)
+    rn = {k: v for k, v in _kernels(connect_asm["rrt_connect.hip"]).items() if "rrt_connect_kernel" in k}
+    assert len(rn) == 14   # dim {2 .. 7, runtime} x obstacle table {LDS, HBM}
+    for name, m in rn.items():
+        assert m["max_flat_workgroup_size"] == 64 and m["private_segment_fixed_size"] == 0 and m["vgpr_spill_count"] == 0, (name, m)
+        assert m["group_segment_fixed_size"] <= 40960, (name, m)
+    body = connect_asm["rrt_connect_se2.hip"].split("rrt_connect_se2_kernelILi768ELb1ELb0EEEvNS_9DevParamsE:")[1].split("s_endpgm")[0]
+    assert "flat_load" not in body and "ds_read_b128" in body and "v_med3_f32" in body   # the shadow scan: LDS reads, top-2 by min / med3
+    assert body.count("s_mul_hi_u32") >= 8            # the checksum's folds on the scalar unit
+    body3 = connect_asm["rrt_connect.hip"].split("rrt_connect_kernelILi3ELb1EEEvNS_9DevParamsE:")[1].split("s_endpgm")[0]
+    assert "flat_load" not in body3
