@@ -22,6 +22,37 @@
 
 using namespace oxhip;
 
+#include <mutex>
+#include <utility>
+namespace {
+std::mutex g_stream_mu;
+std::vector<std::pair<int, hipStream_t>> g_stream_pool;
+constexpr size_t kStreamPoolMax = 32;
+}
+namespace oxhip {
+hipError_t oxhip_stream_acquire(int device, hipStream_t* out) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        for (size_t i = g_stream_pool.size(); i-- > 0;)
+            if (g_stream_pool[i].first == device) {
+                *out = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void oxhip_stream_release(int device, hipStream_t s) {
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        if (g_stream_pool.size() < kStreamPoolMax) { g_stream_pool.emplace_back(device, s); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+}  // namespace oxhip
+
 struct oxhip_rrt_batch {
     oxhip_rrt_config cfg{};
     DevParams dp{};
@@ -202,7 +233,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
 
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    chk(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    chk(oxhip_stream_acquire(cfg->device, &b->stream));
     chk(hipEventCreate(&b->ev0));
     chk(hipEventCreate(&b->ev1));
     chk(b->tree.alloc((size_t)P * dim * cap));
@@ -237,7 +268,7 @@ int32_t oxhip_rrt_batch_create(const oxhip_rrt_config* cfg, oxhip_rrt_batch** ou
             dp.pool_share = (uint32_t)share;
             hipError_t ew = hipSuccess;
             auto chkw = [&](hipError_t r) { if (ew == hipSuccess) ew = r; };
-            chkw(hipStreamCreateWithFlags(&b->stream2, hipStreamNonBlocking));
+            chkw(oxhip_stream_acquire(cfg->device, &b->stream2));
             for (auto& ev : b->ev_seg) chkw(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             chkw(hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
             chkw(b->pool.alloc((size_t)P * share + 64));   // (+ padding: masked lanes of the wiring kernel read one entry past an empty list)
@@ -364,12 +395,12 @@ int32_t oxhip_rrt_batch_destroy(oxhip_rrt_batch* b) {
     if (!b) return OXHIP_OK;
     (void)hipSetDevice(b->cfg.device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
-    if (b->stream2) { (void)hipStreamSynchronize(b->stream2); (void)hipStreamDestroy(b->stream2); }
+    if (b->stream2) oxhip_stream_release(b->cfg.device, b->stream2);
     for (auto ev : b->ev_seg) if (ev) (void)hipEventDestroy(ev);
     if (b->ev_join) (void)hipEventDestroy(b->ev_join);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
-    if (b->stream) (void)hipStreamDestroy(b->stream);
+    if (b->stream) oxhip_stream_release(b->cfg.device, b->stream);
     if (b->h_states) (void)hipHostFree(b->h_states);
     delete b;
     return OXHIP_OK;
@@ -1009,7 +1040,8 @@ int32_t oxhip_nn_argmin_batch(int32_t device, uint32_t dim, const double* nodes,
         total += n_nodes[q];
     }
     TmpStream ts;
-    HIP_TRY(hipStreamCreate(&ts.s));
+    HIP_TRY(oxhip_stream_acquire(device, &ts.s));
+    ts.device = device;
     DevBuf<double> d_nodes, d_q, d_dist;
     DevBuf<uint64_t> d_off;
     DevBuf<uint32_t> d_n, d_idx;
@@ -1032,7 +1064,8 @@ int32_t oxhip_distance_batch(int32_t device, uint32_t dim, const double* a, cons
     if (n == 0) return OXHIP_OK;
     OX_TRY(select_device(device));
     TmpStream ts;
-    HIP_TRY(hipStreamCreate(&ts.s));
+    HIP_TRY(oxhip_stream_acquire(device, &ts.s));
+    ts.device = device;
     DevBuf<double> da, db, dout;
     OX_TRY(to_device(da, a, (size_t)n * dim, ts.s));
     OX_TRY(to_device(db, b, (size_t)n * dim, ts.s));
@@ -1049,7 +1082,8 @@ int32_t oxhip_interpolate_batch(int32_t device, uint32_t dim, const double* from
     if (n == 0) return OXHIP_OK;
     OX_TRY(select_device(device));
     TmpStream ts;
-    HIP_TRY(hipStreamCreate(&ts.s));
+    HIP_TRY(oxhip_stream_acquire(device, &ts.s));
+    ts.device = device;
     DevBuf<double> da, db, dt, dout;
     OX_TRY(to_device(da, from, (size_t)n * dim, ts.s));
     OX_TRY(to_device(db, to, (size_t)n * dim, ts.s));
@@ -1097,7 +1131,8 @@ int32_t oxhip_f64_op_batch(int32_t device, uint32_t op, const double* a, const d
     if (n == 0) return OXHIP_OK;
     OX_TRY(select_device(device));
     TmpStream ts;
-    HIP_TRY(hipStreamCreate(&ts.s));
+    HIP_TRY(oxhip_stream_acquire(device, &ts.s));
+    ts.device = device;
     DevBuf<double> da, db, dc, dout;
     OX_TRY(to_device(da, a, n, ts.s));
     if (b) OX_TRY(to_device(db, b, n, ts.s));
@@ -1114,7 +1149,8 @@ int32_t oxhip_se2_op_batch(int32_t device, uint32_t op, const double* a, const d
     if (n == 0) return OXHIP_OK;
     OX_TRY(select_device(device));
     TmpStream ts;
-    HIP_TRY(hipStreamCreate(&ts.s));
+    HIP_TRY(oxhip_stream_acquire(device, &ts.s));
+    ts.device = device;
     DevBuf<double> da, db, dt, dout;
     OX_TRY(to_device(da, a, (size_t)3 * n, ts.s));
     OX_TRY(to_device(db, b, (size_t)3 * n, ts.s));
@@ -1130,7 +1166,8 @@ int32_t oxhip_rng_u64_batch(int32_t device, uint64_t seed, uint64_t stream, uint
     if (n == 0) return OXHIP_OK;
     OX_TRY(select_device(device));
     TmpStream ts;
-    HIP_TRY(hipStreamCreate(&ts.s));
+    HIP_TRY(oxhip_stream_acquire(device, &ts.s));
+    ts.device = device;
     DevBuf<uint64_t> dout;
     HIP_TRY(dout.alloc(n));
     launch_rng_u64(seed, stream, n, dout.p, ts.s);

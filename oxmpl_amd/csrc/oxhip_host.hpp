@@ -92,9 +92,17 @@ struct DevBuf {
     }
 };
 
+// Streams are recycled.  On this stack hipStreamCreate takes 1.5 ms and hipStreamDestroy 1.7 ms (rocprofv3 --hip-trace of
+// tools/bench_single.py, profiles/r3_single/hip_api_stats.csv) -- more than every other call of a one-problem Planner::solve together,
+// kernel included -- so a destroyed planner's stream (drained) goes to a small per-device pool and the next create takes it from
+// there.  Pooled streams live until the process ends.
+hipError_t oxhip_stream_acquire(int device, hipStream_t* out);   // non-blocking streams; `device` is the current device
+void oxhip_stream_release(int device, hipStream_t s);            // synchronises s first
+
 struct TmpStream {
     hipStream_t s = nullptr;
-    ~TmpStream() { if (s) (void)hipStreamDestroy(s); }
+    int device = 0;
+    ~TmpStream() { if (s) oxhip_stream_release(device, s); }
 };
 template <typename T>
 int32_t to_device(DevBuf<T>& buf, const T* host, size_t n, hipStream_t s) {

@@ -203,7 +203,7 @@ int32_t oxhip_prm_create(const oxhip_prm_config* cfg, oxhip_prm** out) {
 
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t r) { if (e == hipSuccess) e = r; };
-    chk(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    chk(oxhip_stream_acquire(cfg->device, &h->stream));
     for (auto& ev : h->ev) chk(hipEventCreate(&ev));
     chk(h->ms.alloc((size_t)dim * cap));
     chk(h->ms32.alloc((size_t)dim * cap));
@@ -230,7 +230,7 @@ int32_t oxhip_prm_destroy(oxhip_prm* h) {
     (void)hipSetDevice(h->cfg.device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream) oxhip_stream_release(h->cfg.device, h->stream);
     delete h;
     return OXHIP_OK;
 }
